@@ -1,0 +1,114 @@
+"""
+synthetic LiDAR-style clouds for the BASELINE.json configurations.
+
+all coordinates are metres, generated in fp64 from `numpy.random.RandomState(seed)`, then rounded to
+fp32-representable values and stored as fp64, so fp32 and fp64 storage of the same cloud are
+bit-equivalent.  used by bench.py, the tests and tests/golden/make_golden.py.
+"""
+
+import numpy as np
+
+
+def _round32(points):
+    return np.ascontiguousarray(points.astype(np.float32).astype(np.float64))
+
+
+def uniform_cloud(n, extent=10.0, seed=0):
+    """config 1: uniform-random cloud in [0, extent)^3."""
+    rs = np.random.RandomState(seed)
+    return _round32(rs.rand(n, 3) * extent)
+
+
+def scene_cloud(n, extent=60.0, n_poles=200, n_spheres=40, seed=1, offset=(0.0, 0.0, 0.0)):
+    """configs 2/3/5: 60 % ground plane on [0,extent]^2 (z ~ N(0, 0.01 m)), 10 % vertical poles
+    (radius 0.05 m, height 6 m, xy jitter N(0, 0.01)), 30 % sphere shells (radius 1.5 m, radial noise
+    N(0, 0.01)).  points are shuffled so row order carries no spatial coherence."""
+    rs = np.random.RandomState(seed)
+    n_ground = int(round(0.6 * n))
+    n_pole = int(round(0.1 * n))
+    n_sphere = n - n_ground - n_pole
+
+    ground = np.empty((n_ground, 3))
+    ground[:, :2] = rs.rand(n_ground, 2) * extent
+    ground[:, 2] = rs.randn(n_ground) * 0.01
+
+    pole_xy = rs.rand(n_poles, 2) * extent
+    which = rs.randint(0, n_poles, n_pole)
+    ang = rs.rand(n_pole) * 2 * np.pi
+    pole = np.empty((n_pole, 3))
+    pole[:, 0] = pole_xy[which, 0] + 0.05 * np.cos(ang) + rs.randn(n_pole) * 0.01
+    pole[:, 1] = pole_xy[which, 1] + 0.05 * np.sin(ang) + rs.randn(n_pole) * 0.01
+    pole[:, 2] = rs.rand(n_pole) * 6.0
+
+    centre = np.empty((n_spheres, 3))
+    centre[:, :2] = rs.rand(n_spheres, 2) * extent
+    centre[:, 2] = 1.5 + rs.rand(n_spheres) * 2.0
+    which = rs.randint(0, n_spheres, n_sphere)
+    direction = rs.randn(n_sphere, 3)
+    direction /= np.linalg.norm(direction, axis=1)[:, None]
+    radius = 1.5 + rs.randn(n_sphere) * 0.01
+    sphere = centre[which] + direction * radius[:, None]
+
+    points = np.concatenate((ground, pole, sphere), axis=0)
+    labels = np.concatenate((
+        np.zeros(n_ground, dtype=np.int32),
+        np.ones(n_pole, dtype=np.int32),
+        np.full(n_sphere, 2, dtype=np.int32)))
+    order = rs.permutation(n)
+    points = points[order] + np.asarray(offset, dtype=np.float64)
+    return _round32(points), labels[order]
+
+
+def morton_sort(points, edge_length):
+    """order rows by the 63-bit Morton code of their `edge_length` cell (config 3 is stored this way:
+    the layout a tiled LiDAR archive would hand over)."""
+    cells = np.floor((points - points.min(0)) / edge_length).astype(np.uint64)
+
+    def spread(v):
+        v = v & np.uint64(0x1FFFFF)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+
+    code = spread(cells[:, 0]) | (spread(cells[:, 1]) << np.uint64(1)) | \
+        (spread(cells[:, 2]) << np.uint64(2))
+    return np.argsort(code, kind="stable")
+
+
+CONFIGS = {
+    # name: (generator kwargs, edge lengths, radii)
+    "c1_uniform_100k": dict(kind="uniform", n=100_000, extent=10.0, seed=0,
+                            edges=[0.25], radii=[0.75]),
+    "c2_scene_1m": dict(kind="scene", n=1_000_000, extent=60.0, n_poles=200, n_spheres=40, seed=1,
+                        edges=[0.10, 0.20, 0.40], radii=[0.30, 0.60, 1.20]),
+    "c3_scene_10m": dict(kind="scene", n=10_000_000, extent=190.0, n_poles=2000, n_spheres=400,
+                         seed=2, edges=[0.05, 0.10, 0.20, 0.40, 0.80],
+                         radii=[0.15, 0.30, 0.60, 1.20, 2.40], morton=0.80),
+}
+
+
+def make_config(name, n=None):
+    """returns (points, labels_or_None, edges, radii) for a named configuration; `n` overrides the
+    point count (same generator, same density when the extent is scaled by the caller)."""
+    cfg = dict(CONFIGS[name])
+    if n is not None:
+        # keep the areal density: scale the extent with sqrt(n)
+        cfg["extent"] = cfg["extent"] * np.sqrt(n / cfg["n"]) if cfg["kind"] == "scene" \
+            else cfg["extent"] * (n / cfg["n"]) ** (1.0 / 3.0)
+        if cfg["kind"] == "scene":
+            cfg["n_poles"] = max(1, int(round(cfg["n_poles"] * n / cfg["n"])))
+            cfg["n_spheres"] = max(1, int(round(cfg["n_spheres"] * n / cfg["n"])))
+        cfg["n"] = n
+    if cfg["kind"] == "uniform":
+        points, labels = uniform_cloud(cfg["n"], cfg["extent"], cfg["seed"]), None
+    else:
+        points, labels = scene_cloud(cfg["n"], cfg["extent"], cfg["n_poles"], cfg["n_spheres"],
+                                     cfg["seed"])
+    if cfg.get("morton"):
+        order = morton_sort(points, cfg["morton"])
+        points = np.ascontiguousarray(points[order])
+        labels = labels[order] if labels is not None else None
+    return points, labels, list(cfg["edges"]), list(cfg["radii"])

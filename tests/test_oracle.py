@@ -1,0 +1,161 @@
+"""
+CPU tests: the oracle (oracle/nimrud_oracle.py) against (a) the reference's own VoxelFilter
+known-answer tests, restated from nimrud/utils/tests/geometry_tests.py:17-279, and (b) the golden
+vectors captured from the imported reference (tests/golden/make_golden.py).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import nimrud_oracle as oracle
+from conftest import assert_features_close
+
+PIPELINE_FIXTURES = ["g1_uniform.npz", "g2_scene.npz", "g3_offset.npz", "g4_lattice.npz"]
+
+
+# ---- reference known-answer tests for the lattice (geometry_tests.py) ------------------------------
+
+def test_lattice_init_validation():
+    # geometry_tests.py:17-80
+    rs = np.random.RandomState(10)
+    for dim in (2, 3):
+        with pytest.raises(ValueError):
+            oracle.Lattice(rs.rand(1, dim) * 100, 0.5)
+        pts = rs.rand(1000, dim) * 100
+        lat = oracle.Lattice(pts, 0.5)
+        assert np.array_equal(lat.minimum_corner, pts.min(0) - 0.25)
+        assert np.array_equal(lat.maximum_corner, pts.max(0) + 0.25)
+    for dim in (1, 4):
+        with pytest.raises(ValueError):
+            oracle.Lattice(rs.rand(1000, dim), 0.5)
+    with pytest.raises(ValueError):
+        oracle.Lattice(rs.rand(10), 0.5)
+    with pytest.raises(ValueError):
+        oracle.Lattice(rs.rand(10, 10, 10), 0.5)
+
+
+def test_lattice_shift_and_overflow():
+    # geometry_tests.py:84-138: 17 bits per axis at e = 0.001 over [0,100]; overflow -> ValueError
+    for dim in (2, 3):
+        pts = np.asarray([[0, 0, 0], [100, 100, 100]])[:, :dim]
+        lat = oracle.Lattice(pts, 0.001)
+        assert np.array_equal(lat.shifts, [17, 34][:dim - 1])
+        assert np.array_equal(lat.widths, [17, 17, 17][:dim])
+        with pytest.raises(ValueError):
+            oracle.Lattice(pts, 0.00001 if dim == 3 else 0.00000001)
+
+
+def test_lattice_masks():
+    # geometry_tests.py:142-158
+    for dim in (2, 3):
+        pts = np.asarray([[0, 0, 0], [100, 100, 100]])[:, :dim]
+        lat = oracle.Lattice(pts, 1)
+        assert np.array_equal(lat.masks, [0b1111111, 0b11111110000000, 0b111111100000000000000][:dim])
+
+
+def test_lattice_bounds():
+    # geometry_tests.py:162-192
+    for dim in (2, 3):
+        lat = oracle.Lattice(np.asarray([[0, 0, 0], [100, 100, 100]])[:, :dim], 1)
+
+        def ok(p):
+            try:
+                lat.check_in_bounds(p)
+            except ValueError:
+                return False
+            return True
+        assert ok(np.zeros((1, dim)) - 0.5)
+        assert not ok(np.zeros((1, dim)) - 1.5)
+        assert ok(np.zeros((1, dim)) + 100.5)
+        assert not ok(np.zeros((1, dim)) + 101.5)
+        assert not ok(np.zeros((1, dim + 1)))
+        assert ok(np.zeros(dim))
+        assert not ok(np.zeros(dim + 1))
+
+
+def test_lattice_known_address():
+    # geometry_tests.py:196-256: point (10,11,12) at e=1 -> address 198026 and back
+    lat = oracle.Lattice(np.asarray([[0, 0, 0], [100, 100, 100]]), 1)
+    assert lat.coordinate_to_address(np.arange(3) + 10)[0] == 198026
+    assert np.allclose(lat.address_to_coordinate(198026).ravel(), np.arange(3) + 10)
+    lat2 = oracle.Lattice(np.asarray([[0, 0], [100, 100]]), 1)
+    assert np.allclose(lat2.address_to_coordinate(lat2.coordinate_to_address([10, 11])).ravel(),
+                       [10, 11])
+
+
+def test_lattice_unique():
+    # geometry_tests.py:261-279
+    for dim in (2, 3):
+        lat = oracle.Lattice(np.asarray([[0, 0, 0], [100, 100, 100]])[:, :dim], 1)
+        pts = np.concatenate([np.zeros((1, dim)) + off for off in np.arange(0, 20, 2)])
+        assert np.array_equal(lat.unique_voxels(np.vstack((pts, pts))), pts)
+
+
+# ---- golden vectors from the imported reference ---------------------------------------------------
+
+@pytest.mark.parametrize("name", PIPELINE_FIXTURES)
+def test_oracle_addresses_match_reference(golden, name):
+    g = golden(name)
+    for s, e in enumerate(g["edges"]):
+        lat = oracle.Lattice(g["points"], e)
+        assert np.array_equal(lat.unique_addresses(g["points"]), g["s%d_addresses" % s])
+        assert np.array_equal(lat.minimum_corner, g["s%d_min_corner" % s])
+        assert np.array_equal(lat.shifts, g["s%d_shifts" % s])
+        assert np.array_equal(lat.widths, g["s%d_widths" % s])
+
+
+@pytest.mark.parametrize("name", PIPELINE_FIXTURES)
+def test_oracle_neighbors_match_reference(golden, name):
+    g = golden(name)
+    pts = g["points"]
+    for s, (e, r) in enumerate(zip(g["edges"], g["radii"])):
+        lat = oracle.Lattice(pts, e)
+        voxels = lat.unique_voxels(pts)
+        off, idx = g["s%d_nbr_offsets" % s], g["s%d_nbr_index" % s]
+        n = len(off) - 1
+        for lists in (oracle.ball_neighbors_kdtree(pts[:n], voxels, r),
+                      oracle.ball_neighbors_bruteforce(pts[:n], voxels, r)):
+            o2, i2 = oracle.neighbors_to_csr(lists)
+            assert np.array_equal(o2, off)
+            assert np.array_equal(i2, idx)
+
+
+@pytest.mark.parametrize("name", PIPELINE_FIXTURES)
+def test_oracle_features_match_reference(golden, name):
+    g = golden(name)
+    pts = g["points"]
+    got = oracle.process(pts, pts, g["edges"], g["radii"])
+    want = g["features"]
+    assert np.array_equal(got[:, ::4], want[:, ::4])
+    assert np.abs(got - want).max() <= 1e-12
+    fast = oracle.process_fast(pts, pts, g["edges"], g["radii"])
+    assert_features_close(fast, want, pts)
+    # the vectorised variant agrees with the faithful one far inside the contract
+    assert np.abs(fast - want)[:, [1, 5 % want.shape[1]]].max() <= 1e-8
+
+
+def test_oracle_operators_match_reference(golden):
+    g = golden("g4_operators.npz")
+    q = g["query"]
+    for key in ("two", "three_collinear", "three", "four_coplanar", "plane_lattice", "line_lattice",
+                "blob"):
+        nb = g[key + "_points"]
+        assert oracle.population(nb) == g[key + "_population"]
+        assert abs(oracle.centroid(q, nb) - g[key + "_centroid"]) <= 1e-15
+        assert np.abs(oracle.pca(nb) - g[key + "_pca"]).max() <= 1e-15
+    # k = 0, 1: the reference raises FloatingPointError out of np.cov; the documented value is zeros
+    for key, nb in (("empty", np.zeros((0, 3))), ("one", np.array([[1.0, 2.0, 3.0]]))):
+        assert str(g[key + "_pca_raises"]) == "FloatingPointError"
+        assert oracle.population(nb) == g[key + "_population"]
+        assert abs(oracle.centroid(q, nb) - g[key + "_centroid"]) <= 1e-15
+        assert np.array_equal(oracle.pca(nb), np.zeros(2))
+        with pytest.raises(FloatingPointError):
+            oracle.pca(nb, strict=True)
+
+
+def test_oracle_forest_matches_reference(golden):
+    g = golden("g5_forest.npz")
+    model = {k: g[k] for k in ("left", "right", "feature", "threshold", "value", "roots", "classes")}
+    proba = oracle.forest_predict_proba(model, g["x"])
+    assert np.abs(proba - g["proba"]).max() <= 1e-15
+    assert np.array_equal(oracle.forest_predict(model, g["x"]), g["label"])
