@@ -1,0 +1,206 @@
+"""
+bench.py - the BASELINE.json metric on MI355X: point-scale feature ops/s of the multiscale
+neighborhood-feature path (10M points x 5 scales), with the achieved-HBM roofline figure of the
+dominant kernel and the reference CPU path timed beside it.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+a "step" is one pass of the hot path over one batch of synthetic input: all scales of
+process_single_core's scale loop (cell keys -> sort -> occupancy index -> fused search/moments/eigen
+kernel, per scale) over a cloud that is already resident in HBM.  with N > 1 every rank owns one
+Morton-contiguous spatial tile of the same size (weak scaling) and a step begins with the halo
+exchange over RCCL.  rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3_scene_10m")
+    ap.add_argument("--points", type=int, default=None, help="points per GPU (default: the config's)")
+    ap.add_argument("--cpu-sample", type=int, default=40000,
+                    help="points of the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(points, edges, radii, sample):
+    """the oracle's faithful restatement of nimrud/minimal (chunked kd-tree query + per-neighborhood
+    numpy operators), one core, on a Morton-contiguous slice of the same cloud."""
+    from oracle import nimrud_oracle as oracle
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:   # noqa: BLE001
+        limiter = None
+    lo = max(0, len(points) // 2 - sample // 2)
+    tile = np.ascontiguousarray(points[lo:lo + sample])
+    t0 = time.perf_counter()
+    oracle.process(tile, tile, edges, radii)
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
+    return {
+        "value": len(tile) * len(edges) / dt,
+        "unit": "point-scales/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d-point Morton-contiguous slice of the same cloud as query and search, %d scales, "
+                  "oracle.process (scipy cKDTree.query_ball_tree in 1000-point chunks + per-"
+                  "neighborhood numpy cov/eigvalsh), %.1f s, host has %d cpus"
+                  % (len(tile), len(edges), dt, os.cpu_count() or 0),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from nimrud_amd import synth, device as nm_device
+    from nimrud_amd.minimal import multiscale
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
+                         % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- synthetic input: one tile per rank, tiles side by side along x ---------------------------
+    cfg = synth.CONFIGS[args.workload]
+    n_points = args.points or cfg["n"]
+    points, _, edges, radii = synth.make_config(args.workload, n=n_points, seed_offset=rank)
+    if world > 1:
+        extent = points[:, 0].max() - points[:, 0].min()
+        points[:, 0] += rank * float(np.ceil(extent))
+    cloud = torch.from_numpy(points).to(dev)
+    n_scales = len(edges)
+    rt = nm_device.get_runtime(dev)
+
+    if world > 1:
+        from nimrud_amd import parallel
+        plan = parallel.TilePlan(cloud, edges, radii)
+
+        def step():
+            return parallel.process_tile(plan)
+    else:
+        out = torch.empty((cloud.shape[0], 4 * n_scales), dtype=torch.float64, device=dev)
+
+        def step():
+            return multiscale.process_gpu(cloud, cloud, edges, radii, out=out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    rt.lib.nm_profile_begin(rt.ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    ms = (ctypes.c_double * 4)()
+    launches = ctypes.c_int64(0)
+    rt.check(rt.lib.nm_profile_end(rt.ctx, ctypes.byref(ms), ctypes.byref(launches)))
+
+    # occupied voxels per scale (for the algorithmic byte count), outside the timed region
+    _, info = multiscale.process_gpu(cloud, cloud, edges, radii, return_info=True) \
+        if world == 1 else (None, plan.last_info())
+    voxels = [i.voxels for i in info]
+    n_local_search = cloud.shape[0] if world == 1 else plan.search_points()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([cloud.shape[0]], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        total_points = int(tot.item())
+    else:
+        total_points = cloud.shape[0]
+
+    if rank == 0:
+        point_scales = total_points * n_scales * args.steps
+        value = point_scales / elapsed
+        # dominant kernel = k_scale_features<7>: per launch it reads the query coordinates (24 B) and
+        # the occupied-voxel set (8 B per voxel as addresses) and writes 4 fp64 features (32 B).
+        nq = cloud.shape[0]
+        alg_bytes = float(np.mean([56.0 * nq + 8.0 * m for m in voxels]))
+        k_ms = ms[2] / max(launches.value, 1)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        record = {
+            "metric": "point-scale feature ops/sec",
+            "value": value,
+            "unit": "point-scales/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d points/GPU plane+pole+sphere scene, %d scales e=%s r=3e, "
+                            "query cloud = search cloud, rows in Morton order of the coarsest cell"
+                            % (args.workload, nq, n_scales, edges),
+                "points_per_gpu": nq,
+                "scales": n_scales,
+                "parallelism": "tiles%d" % world,
+                "search_points_incl_halo": int(n_local_search),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_scale_features<7>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "alg_bytes_per_launch": alg_bytes,
+                "kernel_ms_avg": k_ms,
+            },
+            "stage_ms_per_step": {
+                "cell_keys_and_sort": ms[0] / args.steps,
+                "index_build": ms[1] / args.steps,
+                "search_feature_kernel": ms[2] / args.steps,
+            },
+            "voxels_per_scale": voxels,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            record["cpu_baseline"] = cpu_baseline(points, edges, radii, args.cpu_sample)
+        else:
+            record["cpu_baseline"] = None
+        print(json.dumps(record))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

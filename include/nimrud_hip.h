@@ -1,0 +1,175 @@
+/*
+ * nimrud_hip.h - C ABI of libnimrud_hip.so: the MI355X (gfx950) implementation of the
+ * grayhem/nimrud multiscale neighborhood-feature hot path (nimrud/minimal).
+ *
+ * The reference has no FFI layer: its boundary is the Python module surface of nimrud.minimal.  Each
+ * entry point below names the reference code it replaces (paths relative to the reference checkout).
+ * The Python package nimrud_amd binds these with ctypes (nimrud_amd/_ffi.py); INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only.  every pointer whose name starts with d_ is DEVICE memory (HBM) owned by the
+ *     caller; the library never allocates or frees caller-visible memory.  scratch memory is passed in
+ *     as (d_work, work_bytes); its required size comes from the matching *_workspace_bytes function.
+ *   - point clouds are row-major fp64 arrays; `stride` is the row pitch in doubles (>= 3), so a
+ *     (N, 3+F) cloud with feature columns is passed without a copy (minimal/README.md:38-40).
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     unless documented otherwise, and returns NM_OK or a negative nm_status.
+ *     nm_last_error(ctx) returns a human-readable message for the last failure on that context.
+ *   - one nm_ctx per (device, host thread).  no global state.
+ */
+#ifndef NIMRUD_HIP_H
+#define NIMRUD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nm_ctx nm_ctx;
+
+typedef enum nm_status {
+    NM_OK = 0,
+    NM_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, stride < 3 ...)            */
+    NM_ERR_LATTICE = -2,     /* lattice cannot be addressed (geometry.py:59-60 ValueError), or is
+                                outside the device path's limits (see nm_lattice)                     */
+    NM_ERR_WORKSPACE = -3,   /* d_work too small                                                       */
+    NM_ERR_HIP = -4,         /* a HIP runtime call failed                                              */
+    NM_ERR_RADIUS = -5       /* radius / edge ratio outside the supported range                        */
+} nm_status;
+
+/*
+ * The bounding lattice of one analysis scale: VoxelFilter.__init__ / _calculate_shift
+ * (nimrud/utils/geometry.py:23-64).  Filled on the host (nimrud_amd/utils/geometry.py does the same
+ * arithmetic as the reference) and passed by pointer.
+ *   min_corner = cloud.min(0) - edge/2          geometry.py:37
+ *   widths     = ceil(log2(span/edge)) per axis geometry.py:56   (sum <= 64, geometry.py:59)
+ *   shifts     = cumsum(widths)[:-1]            geometry.py:62
+ * Device-path limits: 3 spatial dimensions, every width in [1, 30].
+ */
+typedef struct nm_lattice {
+    double  min_corner[3];
+    double  edge;
+    int32_t widths[3];
+    int32_t shifts[2];
+} nm_lattice;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+
+int         nm_create(nm_ctx** out, int device);
+void        nm_destroy(nm_ctx* ctx);
+const char* nm_last_error(const nm_ctx* ctx);
+/* library ABI version (bumped on any signature change) */
+int         nm_abi_version(void);
+
+/* ---- in-library stage timing ----------------------------------------------------------------------
+ * between nm_profile_begin and nm_profile_end every nm_scale_features call brackets its stages with
+ * HIP events on the caller's stream.  nm_profile_end synchronises on them and returns the summed
+ * device time in milliseconds: ms[0] cell keys + radix sort, ms[1] occupancy index build,
+ * ms[2] the fused search/feature kernel, ms[3] reserved; *launches = fused-kernel launches timed.
+ * used by bench.py for the roofline figure; no reference counterpart (the reference's verbose mode
+ * prints wall time per scale, multiscale.py:47-65).                                                */
+int nm_profile_begin(nm_ctx* ctx);
+int nm_profile_end(nm_ctx* ctx, double* ms, int64_t* launches);
+
+/* ---- cloud bounds -------------------------------------------------------------------------------
+ * per-axis min and max of a cloud: the `points.min(0)` / `points.max(0)` of geometry.py:37-38.
+ * d_minmax receives 6 doubles {min x,y,z, max x,y,z}.  the host turns them into an nm_lattice.    */
+int nm_bounds(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+              double* d_minmax, void* stream);
+
+/* ---- voxelize -----------------------------------------------------------------------------------
+ * VoxelFilter.coordinate_to_address + numpy.unique (geometry.py:103-116, 148-150): the sorted
+ * distinct 64-bit voxel addresses x + (y << shifts[0]) + (z << shifts[1]) of the cells
+ * floor((p - min_corner)/edge) occupied by the cloud.  position in this array is the reference's
+ * search-voxel index.  d_addr_out needs room for n entries; *d_count (device int64) receives M.
+ * points outside the lattice make the call fail the way _check_in_bounds does (geometry.py:95-97):
+ * d_count[1] receives the number of out-of-bounds points (the host raises ValueError when != 0).  */
+size_t nm_voxelize_workspace_bytes(int64_t n);
+int nm_voxelize(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const nm_lattice* lat,
+                int64_t* d_addr_out, int64_t* d_count, void* d_work, size_t work_bytes, void* stream);
+
+/* VoxelFilter.coordinate_to_address (geometry.py:103-116) without the unique: one address per point,
+ * in point order.  *d_oob (device int64, nullable) receives the number of points whose cell lies
+ * outside [0, 2^width) on some axis (they are clamped); the bounds check proper
+ * (_check_in_bounds, geometry.py:83-99) is done by the host with nm_bounds.                         */
+int nm_coordinate_to_address(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                             const nm_lattice* lat, int64_t* d_addr_out, int64_t* d_oob,
+                             void* stream);
+
+/* VoxelFilter.address_to_coordinate (geometry.py:120-138): centre = cell*e + min_corner + e*0.5,
+ * evaluated left to right in fp64 without fused multiply-add.  d_xyz_out is (m,3) row-major.       */
+int nm_address_to_coordinate(nm_ctx* ctx, const int64_t* d_addr, int64_t m, const nm_lattice* lat,
+                             double* d_xyz_out, void* stream);
+
+/* ---- one analysis scale, fused -------------------------------------------------------------------
+ * one_scale_single_core (nimrud/minimal/multiscale.py:70-123) in one call:
+ *   voxel-filter the search cloud (multiscale.py:76-77), find for every query point all voxel
+ *   centres with Euclidean distance <= radius (cKDTree.query_ball_tree, multiscale.py:87-103;
+ *   inclusive, ((dx*dx + dy*dy) + dz*dz) <= r*r in fp64), and write per query point
+ *     [population, ||q - centroid||, l1/(l1+l2+l3), l2/(l1+l2+l3)]      features.py:21-57
+ *   (eigenvalues of the ddof=1 covariance, descending) into d_feat[row*feat_stride + 0..3].
+ * rows are in query order.  feat_stride is in doubles (4*S for the (Nq,4S) matrix of
+ * process_single_core, with d_feat pre-offset by 4*s for scale s: multiscale.py:56).
+ * neighborhoods with fewer than 2 voxels get zero eigen-features, empty ones zero centroid
+ * (multiscale.py:4-5).  d_info (device int64[4], nullable) receives {M = number of occupied voxels,
+ * number of neighborhoods with population < 2, passes taken by the search kernel, reserved}.
+ * the query cloud may be the search cloud (same pointer, size and stride): it is then indexed once. */
+size_t nm_scale_workspace_bytes(int64_t n_query, int64_t n_search, const nm_lattice* lat);
+int nm_scale_features(nm_ctx* ctx,
+                      const double* d_query, int64_t n_query, int64_t query_stride,
+                      const double* d_search, int64_t n_search, int64_t search_stride,
+                      const nm_lattice* lat, double radius,
+                      double* d_feat, int64_t feat_stride, int64_t* d_info,
+                      void* d_work, size_t work_bytes, void* stream);
+
+/* ---- neighbor lists (parity / inspection mode) -----------------------------------------------------
+ * the neighbor_idx lists of multiscale.py:103 as CSR.  two calls: with d_nbr_index == NULL the
+ * per-query counts are written to d_nbr_count (int32[n_query]); the caller turns them into offsets
+ * (exclusive prefix sum, int64[n_query+1]) and calls again with d_nbr_offsets and d_nbr_index
+ * (int64[total]).  indices are positions in the sorted unique address array d_addr (from
+ * nm_voxelize), ascending within a query point.                                                     */
+int nm_scale_neighbors(nm_ctx* ctx,
+                       const double* d_query, int64_t n_query, int64_t query_stride,
+                       const int64_t* d_addr, int64_t m, const nm_lattice* lat, double radius,
+                       int32_t* d_nbr_count, const int64_t* d_nbr_offsets, int64_t* d_nbr_index,
+                       void* stream);
+
+/* ---- explicit neighborhoods -----------------------------------------------------------------------
+ * features.population / centroid / pca (features.py:21-57) for a batch of explicit neighborhoods
+ * given as CSR over a point array: neighborhood b is d_points[d_offsets[b] .. d_offsets[b+1]) (rows
+ * of 3 doubles), d_query row b is its query point.  output as in nm_scale_features.                 */
+int nm_neighborhood_features(nm_ctx* ctx, const double* d_points, const int64_t* d_offsets,
+                             const double* d_query, int64_t n_neighborhoods,
+                             double* d_feat, int64_t feat_stride, void* stream);
+
+/* ---- classifier slot -------------------------------------------------------------------------------
+ * nimrud/minimal/classification.py is a stub; the reference's classifier is sklearn's
+ * RandomForestClassifier (prototypes/apc.py:1463) applied per point with predict / predict_proba
+ * (apc.py:1022,1034).  the forest is passed flattened: node arrays of all trees concatenated,
+ * children are absolute node indices (-1 at a leaf), `value` is the per-node class distribution
+ * normalised to sum 1, `roots` the root node of each tree.  features are cast to fp32 and a sample
+ * goes left when (double)(float)x[feature] <= threshold, as sklearn does.
+ * d_proba (n, n_classes) row-major (nullable), d_label int32[n] = argmax class position (nullable). */
+typedef struct nm_forest {
+    const int32_t* d_left;
+    const int32_t* d_right;
+    const int32_t* d_feature;
+    const double*  d_threshold;
+    const double*  d_value;
+    const int32_t* d_roots;
+    int32_t n_nodes;
+    int32_t n_trees;
+    int32_t n_classes;
+    int32_t n_features;
+} nm_forest;
+
+int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, int64_t n,
+                   int64_t feat_stride, double* d_proba, int32_t* d_label, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIMRUD_HIP_H */

@@ -1,0 +1,127 @@
+// nm_api.hip - context management and the classifier slot (random-forest evaluation).
+//
+// reference code replaced by nm_forest_eval: sklearn RandomForestClassifier.predict / predict_proba
+// at nimrud/prototypes/apc.py:1008,1022,1034,1745,1752 (nimrud/minimal/classification.py is a stub).
+
+#include "nm_common.h"
+
+extern "C" int nm_abi_version(void) { return 1; }
+
+extern "C" int nm_create(nm_ctx** out, int device)
+{
+    if (!out) return NM_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return NM_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return NM_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return NM_ERR_HIP;
+    nm_ctx* ctx = new nm_ctx();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return NM_OK;
+}
+
+extern "C" void nm_destroy(nm_ctx* ctx)
+{
+    if (!ctx) return;
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+extern "C" int nm_profile_begin(nm_ctx* ctx)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    ctx->profiling = true;
+    ctx->events_used = 0;
+    return NM_OK;
+}
+
+extern "C" int nm_profile_end(nm_ctx* ctx, double* ms, int64_t* launches)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    ctx->profiling = false;
+    double acc[4] = {0, 0, 0, 0};
+    int64_t calls = (int64_t)(ctx->events_used / 4);
+    for (int64_t k = 0; k < calls; ++k) {
+        NM_HIP(ctx, hipEventSynchronize(ctx->events[4 * k + 3]));
+        for (int st = 0; st < 3; ++st) {
+            float t = 0.f;
+            NM_HIP(ctx, hipEventElapsedTime(&t, ctx->events[4 * k + st], ctx->events[4 * k + st + 1]));
+            acc[st] += (double)t;
+        }
+    }
+    if (ms) for (int i = 0; i < 4; ++i) ms[i] = acc[i];
+    if (launches) *launches = calls;
+    ctx->events_used = 0;
+    return NM_OK;
+}
+
+extern "C" const char* nm_last_error(const nm_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+// one lane per point; all lanes of a wave walk the same tree at the same time, so node fetches of the
+// upper levels are wave-uniform and cache resident.  proba is accumulated in tree order, like
+// sklearn's accumulate-then-divide.
+constexpr int NM_MAX_CLASSES = 16;
+
+__global__ __launch_bounds__(256) void k_forest_eval(nm_forest F, const double* __restrict__ feat,
+                                                     int64_t n, int64_t fstride,
+                                                     double* __restrict__ proba,
+                                                     int32_t* __restrict__ label)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* x = feat + i * fstride;
+    double acc[NM_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < NM_MAX_CLASSES; ++c) acc[c] = 0.0;
+    for (int t = 0; t < F.n_trees; ++t) {
+        int32_t node = F.d_roots[t];
+        for (;;) {
+            const int32_t left = F.d_left[node];
+            if (left < 0) break;
+            // sklearn casts X to float32 and compares against the float64 threshold
+            const double v = (double)(float)x[F.d_feature[node]];
+            node = (v <= F.d_threshold[node]) ? left : F.d_right[node];
+        }
+        const double* val = F.d_value + (int64_t)node * F.n_classes;
+#pragma unroll
+        for (int c = 0; c < NM_MAX_CLASSES; ++c)
+            if (c < F.n_classes) acc[c] += val[c];
+    }
+    int best = 0;
+    double bestv = -1.0;
+    const double inv = 1.0 / (double)F.n_trees;
+#pragma unroll
+    for (int c = 0; c < NM_MAX_CLASSES; ++c) {
+        if (c < F.n_classes) {
+            const double pr = acc[c] / (double)F.n_trees;
+            (void)inv;
+            if (proba) proba[i * F.n_classes + c] = pr;
+            if (pr > bestv) {   // first maximum wins, like numpy.argmax
+                bestv = pr;
+                best = c;
+            }
+        }
+    }
+    if (label) label[i] = best;
+}
+
+extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, int64_t n,
+                              int64_t feat_stride, double* d_proba, int32_t* d_label, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (!forest || n < 0 || (n > 0 && !d_feat) || (!d_proba && !d_label))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: bad arguments");
+    if (forest->n_classes < 1 || forest->n_classes > NM_MAX_CLASSES)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: n_classes must be in [1,%d]", NM_MAX_CLASSES);
+    if (forest->n_trees < 1 || forest->n_features < 1 || feat_stride < forest->n_features)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: bad forest shape");
+    if (n == 0) return NM_OK;
+    k_forest_eval<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(*forest, d_feat, n,
+                                                                          feat_stride, d_proba,
+                                                                          d_label);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}

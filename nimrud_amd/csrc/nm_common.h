@@ -1,0 +1,181 @@
+// nm_common.h - shared host/device definitions for libnimrud_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/nimrud_hip.h"
+
+struct nm_ctx {
+    int device;
+    std::string error;
+    int num_cus;
+    // stage timing (nm_profile_begin/end): events[4*k .. 4*k+3] bracket the three stages of call k
+    bool profiling = false;
+    std::vector<hipEvent_t> events;
+    size_t events_used = 0;
+};
+
+// next profiling event recorded on `s`, or a no-op when profiling is off
+static inline void nm_profile_mark(nm_ctx* ctx, hipStream_t s)
+{
+    if (!ctx->profiling) return;
+    if (ctx->events_used == ctx->events.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ctx->events.push_back(e);
+    }
+    (void)hipEventRecord(ctx->events[ctx->events_used++], s);
+}
+
+#define NM_FAIL(ctx, code, ...)                                   \
+    do {                                                          \
+        char _buf[512];                                           \
+        snprintf(_buf, sizeof(_buf), __VA_ARGS__);                \
+        if (ctx) (ctx)->error = _buf;                             \
+        return (code);                                            \
+    } while (0)
+
+#define NM_HIP(ctx, call)                                                                 \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess)                                                             \
+            NM_FAIL(ctx, NM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e));      \
+    } while (0)
+
+// ---- superblock ("sb") geometry of the occupancy index -------------------------------------------
+// the occupied lattice cells of one scale are stored as a sparse set of dense leaves.  a leaf covers
+// SBX x SBY x SBZ = 32 x 8 x 8 cells and is 64 row-words of 32 bits: word (lz*8 + ly), bit lx.
+// rows run along x because the reference packs x in the low address bits (geometry.py:111-115).
+constexpr int NM_SBX_BITS = 5;
+constexpr int NM_SBY_BITS = 3;
+constexpr int NM_SBZ_BITS = 3;
+constexpr int NM_LOCAL_BITS = NM_SBX_BITS + NM_SBY_BITS + NM_SBZ_BITS;   // 11
+constexpr int NM_LEAF_WORDS = 1 << (NM_SBY_BITS + NM_SBZ_BITS);          // 64 x u32 = 256 B
+constexpr uint64_t NM_HASH_EMPTY = ~0ull;
+
+// device view of a lattice plus derived constants
+struct LatticeDev {
+    double min_x, min_y, min_z;
+    double edge;
+    double half_edge;           // edge * 0.5 (exact)
+    int32_t wx, wy, wz;         // address widths (geometry.py:56)
+    int32_t s0, s1;             // address shifts (geometry.py:62)
+    int32_t bx, by, bz;         // bits of the superblock coordinate per axis: max(w - local, 0)
+    int32_t keybits;            // significant bits of the sort key
+};
+
+static inline LatticeDev make_lattice_dev(const nm_lattice* lat)
+{
+    LatticeDev d;
+    d.min_x = lat->min_corner[0];
+    d.min_y = lat->min_corner[1];
+    d.min_z = lat->min_corner[2];
+    d.edge = lat->edge;
+    d.half_edge = lat->edge * 0.5;
+    d.wx = lat->widths[0];
+    d.wy = lat->widths[1];
+    d.wz = lat->widths[2];
+    d.s0 = lat->shifts[0];
+    d.s1 = lat->shifts[1];
+    d.bx = d.wx > NM_SBX_BITS ? d.wx - NM_SBX_BITS : 0;
+    d.by = d.wy > NM_SBY_BITS ? d.wy - NM_SBY_BITS : 0;
+    d.bz = d.wz > NM_SBZ_BITS ? d.wz - NM_SBZ_BITS : 0;
+    d.keybits = NM_LOCAL_BITS + d.bx + d.by + d.bz;
+    return d;
+}
+
+static inline int validate_lattice(nm_ctx* ctx, const nm_lattice* lat)
+{
+    if (!lat) NM_FAIL(ctx, NM_ERR_INVALID, "lattice is null");
+    if (!(lat->edge > 0.0)) NM_FAIL(ctx, NM_ERR_LATTICE, "edge length must be positive");
+    int sum = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (lat->widths[a] < 1 || lat->widths[a] > 30)
+            NM_FAIL(ctx, NM_ERR_LATTICE,
+                    "axis %d address width %d outside the device path's range [1,30]", a,
+                    lat->widths[a]);
+        sum += lat->widths[a];
+    }
+    if (sum > 64) NM_FAIL(ctx, NM_ERR_LATTICE, "edge length is too small to address this space");
+    if (lat->shifts[0] != lat->widths[0] || lat->shifts[1] != lat->widths[0] + lat->widths[1])
+        NM_FAIL(ctx, NM_ERR_LATTICE, "shifts are not the cumulative widths");
+    return NM_OK;
+}
+
+// the occupancy index of one scale (all pointers into the caller's workspace)
+struct IndexDev {
+    uint64_t* hash_key;      // open-addressing table of superblock keys (NM_HASH_EMPTY = free)
+    uint32_t* hash_val;      // leaf number of the key in the same slot
+    uint32_t hash_mask;      // capacity - 1 (capacity is a power of two)
+    uint32_t* leaf;          // leaves, NM_LEAF_WORDS words each
+    uint32_t leaf_capacity;  // leaves the workspace has room for
+    uint32_t* counters;      // [0] leaves allocated, [1] occupied cells M (low), [2] overflow flag
+};
+
+#if defined(__HIPCC__)
+
+// ---- exact lattice arithmetic (device) ---------------------------------------------------------------
+// floor((p - min_corner) / e) exactly as geometry.py:108: fp64 subtract, IEEE divide, floor.
+// compiled with -ffp-contract=off so nothing fuses.
+__device__ __forceinline__ double nm_cell_f(double p, double mn, double e) { return floor((p - mn) / e); }
+
+// voxel centre exactly as geometry.py:137: (cell * e + min_corner) + e*0.5, left to right
+__device__ __forceinline__ double nm_centre(int32_t cell, double mn, double e, double he)
+{
+    double t = (double)cell * e;
+    t = t + mn;
+    return t + he;
+}
+
+__device__ __forceinline__ int32_t nm_clamp_cell(double c)
+{
+    // cells of points far outside the lattice are clamped; the callers treat anything outside
+    // [0, 2^w) as "no such cell"
+    c = fmin(fmax(c, -1073741824.0), 1073741823.0);
+    return (int32_t)c;
+}
+
+// sort key: [sbz | sbx | sby | lz:3 | ly:3 | lx:5].  consecutive keys run along x inside a leaf; the
+// next leaf in key order is the y neighbour, so a run of queries that straddles two leaves stays
+// narrow in x.
+__device__ __forceinline__ uint64_t nm_sb_key(uint32_t sbx, uint32_t sby, uint32_t sbz,
+                                              const LatticeDev& L)
+{
+    return ((uint64_t)sbz << (L.bx + L.by)) | ((uint64_t)sbx << L.by) | (uint64_t)sby;
+}
+
+__device__ __forceinline__ uint64_t nm_cell_key(uint32_t cx, uint32_t cy, uint32_t cz,
+                                                const LatticeDev& L)
+{
+    uint64_t sb = nm_sb_key(cx >> NM_SBX_BITS, cy >> NM_SBY_BITS, cz >> NM_SBZ_BITS, L);
+    uint32_t local = ((cz & 7u) << 8) | ((cy & 7u) << 5) | (cx & 31u);
+    return (sb << NM_LOCAL_BITS) | local;
+}
+
+__device__ __forceinline__ uint32_t nm_hash64(uint64_t k)
+{
+    uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h;
+}
+
+// leaf number of a superblock, or -1
+__device__ __forceinline__ int32_t nm_hash_find(const IndexDev& I, uint64_t key)
+{
+    uint32_t slot = nm_hash64(key) & I.hash_mask;
+    for (;;) {
+        uint64_t k = I.hash_key[slot];
+        if (k == key) return (int32_t)I.hash_val[slot];
+        if (k == NM_HASH_EMPTY) return -1;
+        slot = (slot + 1) & I.hash_mask;
+    }
+}
+
+#endif  // __HIPCC__

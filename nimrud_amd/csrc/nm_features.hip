@@ -1,0 +1,772 @@
+// nm_features.hip - the fused per-scale kernel: lattice ball search + exact integer moments +
+// fp64 3x3 symmetric eigen-solve + feature assembly.
+//
+// reference code replaced:
+//   nimrud/minimal/multiscale.py:87-123  (kd-tree radius search, per-neighborhood feature loops)
+//   nimrud/minimal/features.py:14-57     (take / population / centroid / pca)
+//
+// why there is no tree: the search set is the set of occupied sites of a cubic lattice
+// (geometry.py:108,137), so the candidates of a query are the W^3 sites around its home cell
+// (W = 2*floor(r/e + 1/2) + 1) and the neighborhood's first and second moments are sums of small
+// integers - exact and order-independent.  only the inclusion test is floating point, and it is
+// evaluated with the reference's own operation order on bit-identical voxel centres:
+//     ((dx*dx + dy*dy) + dz*dz) <= r*r        (scipy ckdtree, p = 2, fp64, no FMA)
+//
+// execution model (gfx950, wave64): one 64-thread workgroup = one wave = 64 consecutive queries of
+// the cell-sorted order, one query per lane.  the wave stages the occupancy bits of the box that
+// covers all its lanes' candidate windows into LDS as 64-bit x-rows (funnel-shifted out of the
+// 32x8x8 leaves of the index), then every lane walks its W*W rows: one LDS read gives the W
+// occupancy bits of a row, W fp64 add/sub pairs give the W inside/outside bits, and a packed LDS
+// lookup turns the surviving bit mask into (count, sum i, sum i^2).  lanes whose windows do not fit
+// the staged box are deferred to another pass of the same wave.
+
+#include "nm_common.h"
+#include "nm_index.h"
+
+constexpr int ROWS_CAP = 512;   // staged (y,z) rows per wave, 8 B each
+constexpr int SBT_CAP = 192;    // superblock slots of the staged box (3 in x)
+constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anchor lane
+
+struct ScaleArgs {
+    const double* query;
+    int64_t nq;
+    int64_t qstride;
+    const uint32_t* order;   // order[slot] = query row processed in sorted slot `slot`
+    LatticeDev L;
+    IndexDev I;
+    double r2;               // radius * radius (fp64 product, as scipy forms it)
+    int32_t dmin;            // first candidate offset (= -(W-1)/2)
+    int32_t W;               // candidates per axis
+    double* feat;
+    int64_t fstride;
+    uint32_t* stats;         // [0] neighborhoods with population < 2, [1] extra passes
+};
+
+// ---- 3x3 symmetric eigenvalues, fp64, non-iterative ------------------------------------------------
+// eigenvalues of [[a00,a01,a02],[a01,a11,a12],[a02,a12,a22]] in descending order.
+// the trigonometric solution of the characteristic cubic is accurate only for the eigenvalue that is
+// well separated from the other two (the other two lose sqrt(eps) when they nearly coincide, which
+// is the normal case here: collinear and coplanar lattice neighborhoods have exact double roots).
+// so: take the separated eigenvalue from the cubic, form its eigenvector from the cross products of
+// the rows of (A - lambda*I), deflate A onto the orthogonal complement and solve the remaining
+// symmetric 2x2 in closed form (hypot form, no cancellation).  all three eigenvalues then carry an
+// absolute error of a few ulp of ||A||, like LAPACK's.
+__device__ __forceinline__ void nm_eig3(double a00, double a01, double a02, double a11, double a12,
+                                        double a22, double& l0, double& l1, double& l2)
+{
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double q = (a00 + a11 + a22) * (1.0 / 3.0);
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    if (!(p2 > 0.0)) {
+        l0 = l1 = l2 = q;
+        return;
+    }
+    const double p = sqrt(p2 * (1.0 / 6.0));
+    const double inv = 1.0 / p;
+    const double c00 = b00 * inv, c11 = b11 * inv, c22 = b22 * inv;
+    const double c01 = a01 * inv, c02 = a02 * inv, c12 = a12 * inv;
+    const double det = c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) +
+                       c02 * (c01 * c12 - c11 * c02);
+    const double r = fmin(fmax(det * 0.5, -1.0), 1.0);
+    const double phi = acos(r) * (1.0 / 3.0);
+    // r >= 0: the largest eigenvalue is the separated one; r < 0: the smallest
+    const bool top = r >= 0.0;
+    const double lam = top ? q + 2.0 * p * cos(phi) : q + 2.0 * p * cos(phi + 2.0943951023931954923);
+
+    // eigenvector of lam: the cross product of two rows of (A - lam*I) with the largest norm
+    const double m00 = a00 - lam, m11 = a11 - lam, m22 = a22 - lam;
+    double x0 = a01 * a12 - a02 * m11, y0 = a02 * a01 - m00 * a12, z0 = m00 * m11 - a01 * a01;  // r0 x r1
+    double x1 = a01 * m22 - a02 * a12, y1 = a02 * a02 - m00 * m22, z1 = m00 * a12 - a01 * a02;  // r0 x r2
+    double x2 = m11 * m22 - a12 * a12, y2 = a12 * a02 - a01 * m22, z2 = a01 * a12 - m11 * a02;  // r1 x r2
+    double n0 = x0 * x0 + y0 * y0 + z0 * z0;
+    double n1 = x1 * x1 + y1 * y1 + z1 * z1;
+    double n2 = x2 * x2 + y2 * y2 + z2 * z2;
+    double vx = x0, vy = y0, vz = z0, nn = n0;
+    if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
+    if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
+    if (!(nn > 0.0)) {
+        // (A - lam*I) has rank <= 1: lam is (numerically) a double root after all; fall back to the
+        // cubic's values, which are then exact enough (all three within rounding of q +- p)
+        const double la = q + 2.0 * p * cos(phi), lc = q + 2.0 * p * cos(phi + 2.0943951023931954923);
+        l0 = la;
+        l2 = lc;
+        l1 = 3.0 * q - la - lc;
+        return;
+    }
+    const double vn = 1.0 / sqrt(nn);
+    vx *= vn; vy *= vn; vz *= vn;
+    // orthonormal basis (u, w) of the complement of v
+    double ux, uy, uz;
+    if (fabs(vx) > fabs(vy)) {
+        const double s = 1.0 / sqrt(vx * vx + vz * vz);
+        ux = -vz * s; uy = 0.0; uz = vx * s;
+    } else {
+        const double s = 1.0 / sqrt(vy * vy + vz * vz);
+        ux = 0.0; uy = vz * s; uz = -vy * s;
+    }
+    const double wx = vy * uz - vz * uy, wy = vz * ux - vx * uz, wz = vx * uy - vy * ux;
+    // 2x2 block of A in that basis
+    const double aux = a00 * ux + a01 * uy + a02 * uz, auy = a01 * ux + a11 * uy + a12 * uz,
+                 auz = a02 * ux + a12 * uy + a22 * uz;
+    const double awx = a00 * wx + a01 * wy + a02 * wz, awy = a01 * wx + a11 * wy + a12 * wz,
+                 awz = a02 * wx + a12 * wy + a22 * wz;
+    const double e00 = ux * aux + uy * auy + uz * auz;
+    const double e01 = ux * awx + uy * awy + uz * awz;
+    const double e11 = wx * awx + wy * awy + wz * awz;
+    const double mid = 0.5 * (e00 + e11), hd = 0.5 * (e00 - e11);
+    const double rad = sqrt(hd * hd + e01 * e01);
+    const double hi = mid + rad, lo = mid - rad;
+    if (top) {
+        l0 = lam; l1 = hi; l2 = lo;
+    } else {
+        l0 = hi; l1 = lo; l2 = lam;
+    }
+}
+
+// features from the integer moments of a neighborhood, in candidate-index space (offset d = i + dmin)
+//   n, S1 = sum of (i,j,k), S2 = sum of outer products; (qx - cx_home ...) = query minus home centre
+__device__ __forceinline__ void nm_features_from_moments(
+    double n, double sx, double sy, double sz, double sxx, double sxy, double sxz, double syy,
+    double syz, double szz, double ux, double uy, double uz, double dmin, double edge, double* out)
+{
+    out[0] = n;
+    out[1] = 0.0;
+    out[2] = 0.0;
+    out[3] = 0.0;
+    if (n < 1.0) return;
+    // centroid (features.py:21-29): mean of the neighbor centres = home centre + e*(S1/n + dmin)
+    double mx = ux - (sx / n + dmin) * edge;
+    double my = uy - (sy / n + dmin) * edge;
+    double mz = uz - (sz / n + dmin) * edge;
+    out[1] = sqrt(mx * mx + my * my + mz * mz);
+    if (n < 2.0) return;   // covariance undefined: zeros (multiscale.py:4-5)
+    // n*(n-1)/e^2 times the ddof=1 covariance (features.py:43), exact in integers:
+    //   n*S2 - S1*S1^T.  normalised eigenvalues are invariant to that scale.
+    double a00 = n * sxx - sx * sx, a01 = n * sxy - sx * sy, a02 = n * sxz - sx * sz;
+    double a11 = n * syy - sy * sy, a12 = n * syz - sy * sz, a22 = n * szz - sz * sz;
+    double l0, l1, l2;
+    nm_eig3(a00, a01, a02, a11, a12, a22, l0, l1, l2);
+    double tr = a00 + a11 + a22;      // = l0 + l1 + l2 (features.py:55)
+    out[2] = l0 / tr;
+    out[3] = l1 / tr;
+}
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+__device__ __forceinline__ void lds_fence()
+{
+    // one wave per workgroup: LDS operations of a wave complete in order, the compiler must not
+    // move accesses across this point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// XCD-aware block -> batch mapping: workgroups are dealt round-robin over the 8 XCDs, so give every
+// XCD one contiguous eighth of the sorted query order; neighbouring batches share leaves in that
+// XCD's L2.  bijective for any grid size.
+__device__ __forceinline__ int64_t nm_xcd_batch(int64_t b, int64_t nb)
+{
+    int64_t xcd = b & 7, q = nb >> 3, r = nb & 7;
+    int64_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
+{
+    static_assert(W >= 3 && W <= 9 && (W & 1), "LUT kernel covers W = 3,5,7,9");
+    __shared__ uint64_t rows[ROWS_CAP];
+    __shared__ int32_t sbt[SBT_CAP];
+    __shared__ uint32_t lut[1 << W];
+
+    const int lane = threadIdx.x;
+    const LatticeDev& L = A.L;
+    const int32_t dmin = A.dmin;
+    const int32_t dmax = dmin + W - 1;
+
+    // packed per-mask sums: bits [0,8) count, [8,20) sum of bit index, [20,32) sum of index^2
+    for (int m = lane; m < (1 << W); m += 64) {
+        uint32_t n = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (m & (1 << i)) {
+                n += 1;
+                s1 += i;
+                s2 += i * i;
+            }
+        lut[m] = n | (s1 << 8) | (s2 << 20);
+    }
+
+    const int64_t batch = nm_xcd_batch(blockIdx.x, gridDim.x);
+    const int64_t slot = batch * 64 + lane;
+    const bool have = slot < A.nq;
+    uint32_t qi = 0;
+    double qx = 0.0, qy = 0.0, qz = 0.0;
+    if (have) {
+        qi = A.order[slot];
+        const double* p = A.query + (int64_t)qi * A.qstride;
+        qx = p[0];
+        qy = p[1];
+        qz = p[2];
+    }
+    const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
+    const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
+    const int32_t hz = nm_clamp_cell(nm_cell_f(qz, L.min_z, L.edge));
+    // a query whose whole candidate window lies outside the lattice has no neighbors
+    const bool far = hx + dmax < 0 || hx + dmin >= (1 << L.wx) || hy + dmax < 0 ||
+                     hy + dmin >= (1 << L.wy) || hz + dmax < 0 || hz + dmin >= (1 << L.wz);
+    bool done = !have || far;
+    if (have && far) {
+        double* o = A.feat + (int64_t)qi * A.fstride;
+        o[0] = 0.0;
+        o[1] = 0.0;
+        o[2] = 0.0;
+        o[3] = 0.0;
+    }
+
+    // squared coordinate differences to the W candidate centres per axis (bit-identical centres)
+    double dx2[W], dy2[W], dz2[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+        double d = qx - nm_centre(hx + dmin + i, L.min_x, L.edge, L.half_edge);
+        dx2[i] = d * d;
+        d = qy - nm_centre(hy + dmin + i, L.min_y, L.edge, L.half_edge);
+        dy2[i] = d * d;
+        d = qz - nm_centre(hz + dmin + i, L.min_z, L.edge, L.half_edge);
+        dz2[i] = d * d;
+    }
+    lds_fence();
+
+    uint32_t passes = 0;
+    for (;;) {
+        const unsigned long long todo = __ballot(!done);
+        if (!todo) break;
+        ++passes;
+        // ---- choose the box: bounding box of the pending lanes if it fits, else a fixed box around
+        //      the first pending lane
+        int32_t lox = wave_min_i32(done ? INT32_MAX : hx), hix = wave_max_i32(done ? INT32_MIN : hx);
+        int32_t loy = wave_min_i32(done ? INT32_MAX : hy), hiy = wave_max_i32(done ? INT32_MIN : hy);
+        int32_t loz = wave_min_i32(done ? INT32_MAX : hz), hiz = wave_max_i32(done ? INT32_MIN : hz);
+        int64_t ex64 = (int64_t)hix - lox + W, ey64 = (int64_t)hiy - loy + W,
+                ez64 = (int64_t)hiz - loz + W;
+        int32_t ox = lox + dmin, oy = loy + dmin, oz = loz + dmin;
+        int32_t ey = (int32_t)ey64, ez = (int32_t)ez64;
+        bool fits = ex64 <= 64 && ey64 <= ROWS_CAP && ez64 <= ROWS_CAP && ey64 * ez64 <= ROWS_CAP;
+        if (fits) {
+            int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - (oy >> NM_SBY_BITS) + 1;
+            int32_t nsz = ((oz + ez - 1) >> NM_SBZ_BITS) - (oz >> NM_SBZ_BITS) + 1;
+            fits = 3 * nsy * nsz <= SBT_CAP;
+        }
+        if (!fits) {
+            const int anchor = __ffsll((long long)todo) - 1;
+            const int32_t ax = __shfl(hx, anchor), ay = __shfl(hy, anchor), az = __shfl(hz, anchor);
+            ox = ax + dmin - (64 - W) / 2;
+            oy = ay + dmin - (ANCHOR_EYZ - W) / 2;
+            oz = az + dmin - (ANCHOR_EYZ - W) / 2;
+            ey = ANCHOR_EYZ;
+            ez = ANCHOR_EYZ;
+        }
+        const bool sel = !done && hx + dmin >= ox && hx + dmax < ox + 64 && hy + dmin >= oy &&
+                         hy + dmax < oy + ey && hz + dmin >= oz && hz + dmax < oz + ez;
+
+        // ---- stage: leaf numbers of the box's superblocks
+        const int32_t sbx0 = ox >> NM_SBX_BITS, sby0 = oy >> NM_SBY_BITS, sbz0 = oz >> NM_SBZ_BITS;
+        const int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - sby0 + 1;
+        const int32_t nsz = ((oz + ez - 1) >> NM_SBZ_BITS) - sbz0 + 1;
+        const int32_t nsb = 3 * nsy * nsz;
+        for (int32_t t = lane; t < nsb; t += 64) {
+            int32_t ix = t % 3, iy = (t / 3) % nsy, iz = t / (3 * nsy);
+            int32_t sx = sbx0 + ix, sy = sby0 + iy, sz = sbz0 + iz;
+            bool ok = sx >= 0 && sy >= 0 && sz >= 0 && sx < (1 << L.bx) && sy < (1 << L.by) &&
+                      sz < (1 << L.bz);
+            sbt[t] = ok ? nm_hash_find(A.I, nm_sb_key((uint32_t)sx, (uint32_t)sy, (uint32_t)sz, L))
+                        : -1;
+        }
+        lds_fence();
+        // ---- stage: 64-bit x-rows of the box, funnel-shifted out of the 32-bit leaf words
+        const int32_t nrows = ey * ez;
+        const uint32_t sh = (uint32_t)(ox & 31);
+        for (int32_t rr = lane; rr < nrows; rr += 64) {
+            int32_t y = oy + rr % ey, z = oz + rr / ey;
+            int32_t t0 = (((z >> NM_SBZ_BITS) - sbz0) * nsy + ((y >> NM_SBY_BITS) - sby0)) * 3;
+            uint32_t wofs = (uint32_t)((z & 7) * 8 + (y & 7));
+            int32_t l0 = sbt[t0], l1 = sbt[t0 + 1], l2 = sbt[t0 + 2];
+            uint32_t w0 = l0 >= 0 ? A.I.leaf[(size_t)l0 * NM_LEAF_WORDS + wofs] : 0u;
+            uint32_t w1 = l1 >= 0 ? A.I.leaf[(size_t)l1 * NM_LEAF_WORDS + wofs] : 0u;
+            uint32_t w2 = l2 >= 0 ? A.I.leaf[(size_t)l2 * NM_LEAF_WORDS + wofs] : 0u;
+            uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+            uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+            rows[rr] = (uint64_t)lo | ((uint64_t)hi << 32);
+        }
+        lds_fence();
+
+        // ---- walk the W*W rows of every selected lane
+        if (sel) {
+            const int32_t rx = hx + dmin - ox;
+            const int32_t rbase = (hz + dmin - oz) * ey + (hy + dmin - oy);
+            uint32_t aj[W], bk[W], cj[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) aj[i] = bk[i] = cj[i] = 0u;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                double pxy[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) pxy[i] = dx2[i] + dy2[j];
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const uint64_t row = rows[rbase + k * ey + j];
+                    const uint32_t occ = (uint32_t)(row >> rx) & ((1u << W) - 1u);
+                    if (__ballot(occ != 0u) == 0ull) continue;   // wave-uniform: nothing occupied
+                    uint32_t outside = 0u;
+#pragma unroll
+                    for (int i = W - 1; i >= 0; --i) {
+                        double s = pxy[i] + dz2[k];
+                        double t = A.r2 - s;     // sign bit set  <=>  s > r^2  (exact)
+                        outside = __builtin_amdgcn_alignbit(
+                            outside, (uint32_t)__double2hiint(t), 31);
+                    }
+                    const uint32_t t = lut[occ & ~outside];
+                    aj[j] += t;
+                    bk[k] += t;
+                    cj[j] += (t & 0xFFu) * (uint32_t)k;
+                }
+            }
+            uint32_t n = 0, sx = 0, sxx = 0, sy = 0, syy = 0, sxy = 0, sz = 0, szz = 0, sxz = 0,
+                     syz = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                uint32_t na = aj[i] & 0xFFu, xa = (aj[i] >> 8) & 0xFFFu, xxa = aj[i] >> 20;
+                uint32_t nb = bk[i] & 0xFFu, xb = (bk[i] >> 8) & 0xFFFu;
+                n += na;
+                sx += xa;
+                sxx += xxa;
+                sy += na * i;
+                syy += na * (i * i);
+                sxy += xa * i;
+                sz += nb * i;
+                szz += nb * (i * i);
+                sxz += xb * i;
+                syz += cj[i] * i;
+            }
+            double out[4];
+            const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
+            const double uy = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
+            const double uz = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
+            nm_features_from_moments((double)n, (double)sx, (double)sy, (double)sz, (double)sxx,
+                                     (double)sxy, (double)sxz, (double)syy, (double)syz,
+                                     (double)szz, ux, uy, uz, (double)dmin, L.edge, out);
+            double* o = A.feat + (int64_t)qi * A.fstride;
+            o[0] = out[0];
+            o[1] = out[1];
+            o[2] = out[2];
+            o[3] = out[3];
+            const unsigned long long degenerate = __ballot(n < 2u);
+            if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
+                atomicAdd(&A.stats[0], (uint32_t)__popcll(degenerate));
+            done = true;
+        } else {
+            // keep the ballot above convergent for lanes that sit this pass out
+        }
+        lds_fence();
+    }
+    if (passes > 1 && lane == 0) atomicAdd(&A.stats[1], passes - 1);
+}
+
+// ---- generic kernel: any W, direct index lookups per lane (no staging).  slow path for unusual
+//      radius/edge ratios; same arithmetic.
+__global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
+{
+    const LatticeDev& L = A.L;
+    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (slot >= A.nq) return;
+    const uint32_t qi = A.order[slot];
+    const double* p = A.query + (int64_t)qi * A.qstride;
+    const double qx = p[0], qy = p[1], qz = p[2];
+    const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
+    const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
+    const int32_t hz = nm_clamp_cell(nm_cell_f(qz, L.min_z, L.edge));
+    const int32_t W = A.W, dmin = A.dmin;
+    double n = 0, sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    for (int32_t k = 0; k < W; ++k) {
+        const int32_t gz = hz + dmin + k;
+        if (gz < 0 || gz >= (1 << L.wz)) continue;
+        double d = qz - nm_centre(gz, L.min_z, L.edge, L.half_edge);
+        const double dz2 = d * d;
+        for (int32_t j = 0; j < W; ++j) {
+            const int32_t gy = hy + dmin + j;
+            if (gy < 0 || gy >= (1 << L.wy)) continue;
+            d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
+            const double dy2 = d * d;
+            int32_t cached_sb = INT32_MIN;
+            uint32_t word = 0;
+            for (int32_t i = 0; i < W; ++i) {
+                const int32_t gx = hx + dmin + i;
+                if (gx < 0 || gx >= (1 << L.wx)) continue;
+                const int32_t sbx = gx >> NM_SBX_BITS;
+                if (sbx != cached_sb) {
+                    cached_sb = sbx;
+                    int32_t leaf = nm_hash_find(
+                        A.I, nm_sb_key((uint32_t)sbx, (uint32_t)(gy >> NM_SBY_BITS),
+                                       (uint32_t)(gz >> NM_SBZ_BITS), L));
+                    word = leaf >= 0 ? A.I.leaf[(size_t)leaf * NM_LEAF_WORDS + (gz & 7) * 8 + (gy & 7)]
+                                     : 0u;
+                }
+                if (!((word >> (gx & 31)) & 1u)) continue;
+                d = qx - nm_centre(gx, L.min_x, L.edge, L.half_edge);
+                const double s = (d * d + dy2) + dz2;
+                if (s <= A.r2) {
+                    n += 1.0;
+                    sx += i;
+                    sy += j;
+                    sz += k;
+                    sxx += (double)i * i;
+                    sxy += (double)i * j;
+                    sxz += (double)i * k;
+                    syy += (double)j * j;
+                    syz += (double)j * k;
+                    szz += (double)k * k;
+                }
+            }
+        }
+    }
+    double out[4];
+    const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
+    const double uy = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
+    const double uz = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
+    nm_features_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, ux, uy, uz, (double)dmin,
+                             L.edge, out);
+    double* o = A.feat + (int64_t)qi * A.fstride;
+    o[0] = out[0];
+    o[1] = out[1];
+    o[2] = out[2];
+    o[3] = out[3];
+    if (n < 2.0) atomicAdd(&A.stats[0], 1u);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+
+__global__ void k_publish_info(const uint32_t* counters, int64_t* info)
+{
+    if (threadIdx.x == 0) {
+        info[0] = counters[1];   // M
+        info[1] = counters[8];   // neighborhoods with population < 2
+        info[2] = counters[9];   // extra passes of the search kernel
+        info[3] = counters[0];   // leaves
+    }
+}
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// candidates per axis: all integer offsets d with |d + 1/2 - f| <= r/e for some f in [0,1), with a
+// guard for rounding in r/e.  a superset is harmless: every candidate is tested exactly.
+static int candidate_width(double radius, double edge, int32_t* dmin)
+{
+    double rho = radius / edge;
+    double m = floor(rho + 0.5 + 1e-9);
+    if (!(m >= 0.0) || m > 1000.0) return -1;
+    *dmin = -(int32_t)m;
+    return 2 * (int32_t)m + 1;
+}
+
+struct ScaleLayout {
+    size_t key_tmp, val_tmp, key_sorted, val_sorted;   // search cloud (and query cloud when shared)
+    size_t qkey_tmp, qval_tmp, qkey_sorted, qval_sorted;
+    size_t sort_temp, sort_temp_bytes;
+    size_t index;
+    IndexLayout ilay;
+    size_t total;
+};
+
+static void scale_layout(int64_t nq, int64_t ns, const LatticeDev& L, bool shared, ScaleLayout* S)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off += align_up(bytes);
+        return at;
+    };
+    S->key_tmp = take((size_t)ns * 8);
+    S->val_tmp = take((size_t)ns * 4);
+    S->key_sorted = take((size_t)ns * 8);
+    S->val_sorted = take((size_t)ns * 4);
+    if (!shared) {
+        S->qkey_tmp = take((size_t)nq * 8);
+        S->qval_tmp = take((size_t)nq * 4);
+        S->qkey_sorted = take((size_t)nq * 8);
+        S->qval_sorted = take((size_t)nq * 4);
+    } else {
+        S->qkey_tmp = S->qval_tmp = S->qkey_sorted = S->qval_sorted = 0;
+    }
+    S->sort_temp_bytes = nm_sort_pairs_temp_bytes(ns > nq ? ns : nq);
+    S->sort_temp = take(S->sort_temp_bytes);
+    nm_index_layout(L, ns, &S->ilay);
+    S->index = take(S->ilay.total);
+    S->total = off;
+}
+
+extern "C" size_t nm_scale_workspace_bytes(int64_t n_query, int64_t n_search, const nm_lattice* lat)
+{
+    if (!lat || n_query < 0 || n_search < 1) return 0;
+    LatticeDev L = make_lattice_dev(lat);
+    ScaleLayout S;
+    // sized for the separate-cloud case so one workspace serves both
+    scale_layout(n_query > 0 ? n_query : 1, n_search, L, false, &S);
+    return S.total;
+}
+
+extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_query,
+                                 int64_t query_stride, const double* d_search, int64_t n_search,
+                                 int64_t search_stride, const nm_lattice* lat, double radius,
+                                 double* d_feat, int64_t feat_stride, int64_t* d_info, void* d_work,
+                                 size_t work_bytes, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (!d_search || n_search < 2 || search_stride < 3 || n_query < 0 || feat_stride < 4 ||
+        !d_work || n_search >= ((int64_t)1 << 31) || n_query >= ((int64_t)1 << 31))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_features: bad arguments");
+    if (n_query > 0 && (!d_query || !d_feat || query_stride < 3))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_features: bad query/feature arguments");
+    int rc = validate_lattice(ctx, lat);
+    if (rc) return rc;
+    if (!(radius >= 0.0)) NM_FAIL(ctx, NM_ERR_RADIUS, "radius must be non-negative");
+    LatticeDev L = make_lattice_dev(lat);
+    if (L.keybits > 64) NM_FAIL(ctx, NM_ERR_LATTICE, "lattice too large for the device sort key");
+    int32_t dmin = 0;
+    int W = candidate_width(radius, lat->edge, &dmin);
+    if (W < 0) NM_FAIL(ctx, NM_ERR_RADIUS, "radius/edge ratio %g is outside the supported range",
+                       radius / lat->edge);
+
+    const bool shared = (d_query == d_search && n_query == n_search && query_stride == search_stride);
+    ScaleLayout S;
+    scale_layout(n_query > 0 ? n_query : 1, n_search, L, shared, &S);
+    if (work_bytes < S.total)
+        NM_FAIL(ctx, NM_ERR_WORKSPACE, "nm_scale_features: workspace %zu < required %zu", work_bytes,
+                S.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)d_work;
+
+    nm_profile_mark(ctx, s);
+    rc = nm_sort_cells(ctx, d_search, n_search, search_stride, L, (uint64_t*)(w + S.key_tmp),
+                       (uint32_t*)(w + S.val_tmp), (uint64_t*)(w + S.key_sorted),
+                       (uint32_t*)(w + S.val_sorted), w + S.sort_temp, S.sort_temp_bytes, s);
+    if (rc) return rc;
+    if (shared) nm_profile_mark(ctx, s);
+    IndexDev I;
+    rc = nm_index_build(ctx, (const uint64_t*)(w + S.key_sorted), n_search, S.ilay, w + S.index, &I,
+                        s);
+    if (rc) return rc;
+
+    const uint32_t* order = (const uint32_t*)(w + S.val_sorted);
+    if (!shared && n_query > 0) {
+        rc = nm_sort_cells(ctx, d_query, n_query, query_stride, L, (uint64_t*)(w + S.qkey_tmp),
+                           (uint32_t*)(w + S.qval_tmp), (uint64_t*)(w + S.qkey_sorted),
+                           (uint32_t*)(w + S.qval_sorted), w + S.sort_temp, S.sort_temp_bytes, s);
+        if (rc) return rc;
+        order = (const uint32_t*)(w + S.qval_sorted);
+    }
+    // profile stages are [keys+sort | index | fused kernel]: four marks per call.  with a separate
+    // query cloud both sorts and the index are booked together under the first stage.
+    if (!shared) nm_profile_mark(ctx, s);
+    nm_profile_mark(ctx, s);
+
+    if (n_query > 0) {
+        ScaleArgs A;
+        A.query = d_query;
+        A.nq = n_query;
+        A.qstride = query_stride;
+        A.order = order;
+        A.L = L;
+        A.I = I;
+        A.r2 = radius * radius;
+        A.dmin = dmin;
+        A.W = W;
+        A.feat = d_feat;
+        A.fstride = feat_stride;
+        A.stats = I.counters + 8;
+        const int blocks = (int)((n_query + 63) / 64);
+        switch (W) {
+            case 3: k_scale_features<3><<<blocks, 64, 0, s>>>(A); break;
+            case 5: k_scale_features<5><<<blocks, 64, 0, s>>>(A); break;
+            case 7: k_scale_features<7><<<blocks, 64, 0, s>>>(A); break;
+            case 9: k_scale_features<9><<<blocks, 64, 0, s>>>(A); break;
+            default: k_scale_features_generic<<<blocks, 64, 0, s>>>(A); break;
+        }
+    }
+    nm_profile_mark(ctx, s);
+    NM_HIP(ctx, hipGetLastError());
+    if (d_info) {
+        // {M, degenerate neighborhoods, extra passes, leaves}: widen the u32 counters on the device
+        k_publish_info<<<1, 64, 0, s>>>(I.counters, d_info);
+    }
+    return NM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// neighbor lists (parity / inspection): per candidate cell, binary-search the sorted unique address
+// array; emitted index = position in that array = the reference's search-voxel index.
+// ---------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int64_t nm_find_address(const int64_t* __restrict__ addr, int64_t m,
+                                                   int64_t key)
+{
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (addr[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < m && addr[lo] == key) ? lo : -1;
+}
+
+__global__ __launch_bounds__(64) void k_scale_neighbors(const double* __restrict__ query, int64_t nq,
+                                                        int64_t qstride,
+                                                        const int64_t* __restrict__ addr, int64_t m,
+                                                        LatticeDev L, double r2, int32_t dmin,
+                                                        int32_t W, int32_t* __restrict__ count,
+                                                        const int64_t* __restrict__ offsets,
+                                                        int64_t* __restrict__ index)
+{
+    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (q >= nq) return;
+    const double* p = query + q * qstride;
+    const double qx = p[0], qy = p[1], qz = p[2];
+    const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
+    const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
+    const int32_t hz = nm_clamp_cell(nm_cell_f(qz, L.min_z, L.edge));
+    int32_t n = 0;
+    int64_t* out = index ? index + offsets[q] : nullptr;
+    // z outer, x inner: ascending address = ascending index
+    for (int32_t k = 0; k < W; ++k) {
+        const int32_t gz = hz + dmin + k;
+        if (gz < 0 || gz >= (1 << L.wz)) continue;
+        double d = qz - nm_centre(gz, L.min_z, L.edge, L.half_edge);
+        const double dz2 = d * d;
+        for (int32_t j = 0; j < W; ++j) {
+            const int32_t gy = hy + dmin + j;
+            if (gy < 0 || gy >= (1 << L.wy)) continue;
+            d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
+            const double dy2 = d * d;
+            for (int32_t i = 0; i < W; ++i) {
+                const int32_t gx = hx + dmin + i;
+                if (gx < 0 || gx >= (1 << L.wx)) continue;
+                d = qx - nm_centre(gx, L.min_x, L.edge, L.half_edge);
+                const double s = (d * d + dy2) + dz2;
+                if (!(s <= r2)) continue;
+                const int64_t a = (int64_t)gx + ((int64_t)gy << L.s0) + ((int64_t)gz << L.s1);
+                const int64_t pos = nm_find_address(addr, m, a);
+                if (pos < 0) continue;
+                if (out) out[n] = pos;
+                ++n;
+            }
+        }
+    }
+    if (count) count[q] = n;
+}
+
+extern "C" int nm_scale_neighbors(nm_ctx* ctx, const double* d_query, int64_t n_query,
+                                  int64_t query_stride, const int64_t* d_addr, int64_t m,
+                                  const nm_lattice* lat, double radius, int32_t* d_nbr_count,
+                                  const int64_t* d_nbr_offsets, int64_t* d_nbr_index, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (n_query < 0 || m < 0 || query_stride < 3 || (n_query > 0 && !d_query) || (m > 0 && !d_addr))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_neighbors: bad arguments");
+    if (!d_nbr_count && !d_nbr_index)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_neighbors: nothing to write");
+    if (d_nbr_index && !d_nbr_offsets)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_neighbors: index output needs offsets");
+    int rc = validate_lattice(ctx, lat);
+    if (rc) return rc;
+    int32_t dmin = 0;
+    int W = candidate_width(radius, lat->edge, &dmin);
+    if (W < 0) NM_FAIL(ctx, NM_ERR_RADIUS, "radius/edge ratio outside the supported range");
+    if (n_query == 0) return NM_OK;
+    LatticeDev L = make_lattice_dev(lat);
+    k_scale_neighbors<<<(int)((n_query + 63) / 64), 64, 0, (hipStream_t)stream>>>(
+        d_query, n_query, query_stride, d_addr, m, L, radius * radius, dmin, W, d_nbr_count,
+        d_nbr_offsets, d_nbr_index);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// explicit neighborhoods: features.population / centroid / pca on arbitrary point sets (CSR)
+// ---------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_neighborhood_features(const double* __restrict__ pts,
+                                                              const int64_t* __restrict__ offsets,
+                                                              const double* __restrict__ query,
+                                                              int64_t nb, double* __restrict__ feat,
+                                                              int64_t fstride)
+{
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= nb) return;
+    const int64_t lo = offsets[b], hi = offsets[b + 1];
+    const double n = (double)(hi - lo);
+    double* o = feat + b * fstride;
+    o[0] = n;
+    o[1] = 0.0;
+    o[2] = 0.0;
+    o[3] = 0.0;
+    if (hi <= lo) return;
+    // mean first, then deviations, like numpy.cov (features.py:43)
+    double mx = 0, my = 0, mz = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        mx += pts[i * 3];
+        my += pts[i * 3 + 1];
+        mz += pts[i * 3 + 2];
+    }
+    mx /= n;
+    my /= n;
+    mz /= n;
+    const double ux = query[b * 3] - mx, uy = query[b * 3 + 1] - my, uz = query[b * 3 + 2] - mz;
+    o[1] = sqrt(ux * ux + uy * uy + uz * uz);
+    if (hi - lo < 2) return;
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        double x = pts[i * 3] - mx, y = pts[i * 3 + 1] - my, z = pts[i * 3 + 2] - mz;
+        a00 += x * x;
+        a01 += x * y;
+        a02 += x * z;
+        a11 += y * y;
+        a12 += y * z;
+        a22 += z * z;
+    }
+    double l0, l1, l2;
+    nm_eig3(a00, a01, a02, a11, a12, a22, l0, l1, l2);
+    const double tr = a00 + a11 + a22;
+    if (tr > 0.0) {
+        o[2] = l0 / tr;
+        o[3] = l1 / tr;
+    }
+}
+
+extern "C" int nm_neighborhood_features(nm_ctx* ctx, const double* d_points, const int64_t* d_offsets,
+                                        const double* d_query, int64_t n_neighborhoods,
+                                        double* d_feat, int64_t feat_stride, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (n_neighborhoods < 0 || feat_stride < 4 ||
+        (n_neighborhoods > 0 && (!d_offsets || !d_query || !d_feat)))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_neighborhood_features: bad arguments");
+    if (n_neighborhoods == 0) return NM_OK;
+    k_neighborhood_features<<<(int)((n_neighborhoods + 63) / 64), 64, 0, (hipStream_t)stream>>>(
+        d_points, d_offsets, d_query, n_neighborhoods, d_feat, feat_stride);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}

@@ -1,0 +1,21 @@
+// nm_index.h - internal interface of the per-scale occupancy index (nm_index.hip)
+#pragma once
+#include "nm_common.h"
+
+struct IndexLayout {
+    uint32_t leaf_capacity;
+    uint32_t hash_capacity;
+    size_t hash_key_bytes, hash_val_bytes, leaf_bytes, counter_bytes, total;
+};
+
+size_t nm_sort_pairs_temp_bytes(int64_t n);
+void nm_index_layout(const LatticeDev& L, int64_t n_search, IndexLayout* out);
+
+// cell keys of a cloud, sorted, with the permutation (val_sorted[i] = original row of sorted slot i)
+int nm_sort_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const LatticeDev& L,
+                  uint64_t* key_tmp, uint32_t* val_tmp, uint64_t* key_sorted, uint32_t* val_sorted,
+                  void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
+
+// hash table + leaves from the sorted keys of the search cloud
+int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const IndexLayout& lay,
+                   void* index_mem, IndexDev* out, hipStream_t s);

@@ -1,0 +1,476 @@
+// nm_index.hip - lattice kernels: cloud bounds, voxel addresses, the per-scale occupancy index.
+//
+// reference code replaced: VoxelFilter (nimrud/utils/geometry.py:23-154).
+// all lattice arithmetic is fp64 and compiled with -ffp-contract=off so that cells and centres are
+// bit-identical to numpy's.
+
+#include "nm_common.h"
+#include "nm_index.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+// ---------------------------------------------------------------------------------------------------
+// bounds: per-axis min/max.  doubles are mapped to order-preserving u64 so that the hardware's
+// integer atomic min/max can be used; a second tiny kernel maps them back.
+// ---------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t nm_order_encode(double v)
+{
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double nm_order_decode(uint64_t k)
+{
+    uint64_t b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+__global__ void k_bounds_init(uint64_t* mm)
+{
+    int t = threadIdx.x;
+    if (t < 3) mm[t] = ~0ull;          // running min
+    else if (t < 6) mm[t] = 0ull;      // running max
+}
+
+__global__ __launch_bounds__(256) void k_bounds(const double* __restrict__ xyz, int64_t n,
+                                                int64_t stride, uint64_t* mm)
+{
+    double lo[3] = {INFINITY, INFINITY, INFINITY};
+    double hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double* p = xyz + i * stride;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double v = p[a];
+            lo[a] = fmin(lo[a], v);
+            hi[a] = fmax(hi[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fmin(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = fmax(hi[a], __shfl_xor(hi[a], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin((unsigned long long*)&mm[a], (unsigned long long)nm_order_encode(lo[a]));
+            atomicMax((unsigned long long*)&mm[3 + a], (unsigned long long)nm_order_encode(hi[a]));
+        }
+    }
+}
+
+__global__ void k_bounds_finish(uint64_t* mm)
+{
+    int t = threadIdx.x;
+    if (t < 6) {
+        double v = nm_order_decode(mm[t]);
+        ((double*)mm)[t] = v;
+    }
+}
+
+extern "C" int nm_bounds(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                         double* d_minmax, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (!d_xyz || !d_minmax || n < 1 || stride < 3)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_bounds: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    uint64_t* mm = (uint64_t*)d_minmax;
+    k_bounds_init<<<1, 64, 0, s>>>(mm);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    k_bounds<<<(int)blocks, 256, 0, s>>>(d_xyz, n, stride, mm);
+    k_bounds_finish<<<1, 64, 0, s>>>(mm);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reference-order voxel addresses (geometry.py:103-116) -> sort -> unique (geometry.py:150)
+// ---------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_addresses(const double* __restrict__ xyz, int64_t n,
+                                                   int64_t stride, LatticeDev L,
+                                                   uint64_t* __restrict__ addr, int64_t* oob_count)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool oob = false;
+    if (i < n) {
+        const double* p = xyz + i * stride;
+        double fx = nm_cell_f(p[0], L.min_x, L.edge);
+        double fy = nm_cell_f(p[1], L.min_y, L.edge);
+        double fz = nm_cell_f(p[2], L.min_z, L.edge);
+        // _check_in_bounds (geometry.py:95-97): min_corner <= p <= max_corner.  in cell terms a
+        // point of the cloud the lattice was built from always lands in [0, 2^w).
+        oob = fx < 0.0 || fy < 0.0 || fz < 0.0 || fx >= (double)(1u << L.wx) ||
+              fy >= (double)(1u << L.wy) || fz >= (double)(1u << L.wz);
+        int64_t cx = (int64_t)nm_clamp_cell(fx), cy = (int64_t)nm_clamp_cell(fy),
+                cz = (int64_t)nm_clamp_cell(fz);
+        // out-of-bounds points are counted (the host raises, as _check_in_bounds does) and clamped
+        cx = min(max(cx, (int64_t)0), (int64_t)((1u << L.wx) - 1u));
+        cy = min(max(cy, (int64_t)0), (int64_t)((1u << L.wy) - 1u));
+        cz = min(max(cz, (int64_t)0), (int64_t)((1u << L.wz) - 1u));
+        addr[i] = (uint64_t)(cx + (cy << L.s0) + (cz << L.s1));
+    }
+    unsigned long long m = __ballot(oob);
+    if (m && oob_count && (threadIdx.x & 63) == 0)
+        atomicAdd((unsigned long long*)oob_count, (unsigned long long)__popcll(m));
+}
+
+extern "C" int nm_coordinate_to_address(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                                        const nm_lattice* lat, int64_t* d_addr_out, int64_t* d_oob,
+                                        void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (n < 0 || stride < 3 || (n > 0 && (!d_xyz || !d_addr_out)))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_coordinate_to_address: bad arguments");
+    int rc = validate_lattice(ctx, lat);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (d_oob) NM_HIP(ctx, hipMemsetAsync(d_oob, 0, sizeof(int64_t), s));
+    if (n == 0) return NM_OK;
+    LatticeDev L = make_lattice_dev(lat);
+    k_addresses<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, (uint64_t*)d_addr_out,
+                                                      d_oob);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+// ordered compaction of run heads of a sorted array: 2048 keys per block, decoupled by one atomic
+// per block is NOT ordered, so voxelize uses a two-pass count / prefix / write over blocks.
+constexpr int UNIQ_BLOCK = 256;
+constexpr int UNIQ_ITEMS = 8;
+constexpr int UNIQ_TILE = UNIQ_BLOCK * UNIQ_ITEMS;
+
+__global__ __launch_bounds__(UNIQ_BLOCK) void k_unique_count(const uint64_t* __restrict__ sorted,
+                                                             int64_t n,
+                                                             uint32_t* __restrict__ tile_count)
+{
+    __shared__ uint32_t wsum[UNIQ_BLOCK / 64];
+    int64_t base = (int64_t)blockIdx.x * UNIQ_TILE;
+    uint32_t c = 0;
+#pragma unroll
+    for (int it = 0; it < UNIQ_ITEMS; ++it) {
+        int64_t i = base + it * UNIQ_BLOCK + threadIdx.x;
+        if (i < n) {
+            uint64_t k = sorted[i];
+            bool head = (i == 0 || sorted[i - 1] != k);
+            c += head ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < UNIQ_BLOCK / 64; ++w) t += wsum[w];
+        tile_count[blockIdx.x] = t;
+    }
+}
+
+// exclusive prefix over the tile counts, one block (tiles <= a few 10^4 even at 5e7 points)
+__global__ __launch_bounds__(1024) void k_tile_prefix(uint32_t* tile_count, int64_t tiles,
+                                                      int64_t* counters)
+{
+    __shared__ uint64_t part[1024];
+    int t = threadIdx.x;
+    int64_t per = (tiles + 1023) / 1024;
+    int64_t lo = t * per, hi = lo + per;
+    if (hi > tiles) hi = tiles;
+    uint64_t s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += tile_count[i];
+    part[t] = s;
+    __syncthreads();
+    // Hillis-Steele over 1024 partials
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint64_t v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t run = (t == 0) ? 0 : part[t - 1];
+    for (int64_t i = lo; i < hi; ++i) {
+        uint32_t c = tile_count[i];
+        tile_count[i] = (uint32_t)run;   // M < 2^32 is guaranteed by n < 2^32 check on the host
+        run += c;
+    }
+    if (t == 1023) counters[0] = (int64_t)part[1023];
+}
+
+__global__ __launch_bounds__(UNIQ_BLOCK) void k_unique_write(const uint64_t* __restrict__ sorted,
+                                                             int64_t n,
+                                                             const uint32_t* __restrict__ tile_base,
+                                                             int64_t* __restrict__ out)
+{
+    __shared__ uint32_t wbase[UNIQ_BLOCK / 64];
+    __shared__ uint32_t running;
+    int64_t base = (int64_t)blockIdx.x * UNIQ_TILE;
+    if (threadIdx.x == 0) running = tile_base[blockIdx.x];
+    __syncthreads();
+    for (int it = 0; it < UNIQ_ITEMS; ++it) {
+        int64_t i = base + it * UNIQ_BLOCK + threadIdx.x;
+        bool head = false;
+        uint64_t k = 0;
+        if (i < n) {
+            k = sorted[i];
+            head = (i == 0 || sorted[i - 1] != k);
+        }
+        unsigned long long m = __ballot(head);
+        int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) wbase[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = running;
+        for (int ww = 0; ww < w; ++ww) off += wbase[ww];
+        if (head) out[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (int64_t)k;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int ww = 0; ww < UNIQ_BLOCK / 64; ++ww) t += wbase[ww];
+            running += t;
+        }
+        __syncthreads();
+    }
+}
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+static size_t sort_keys_temp_bytes(int64_t n)
+{
+    size_t temp = 0;
+    (void)rocprim::radix_sort_keys(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                                   (size_t)n, 0, 64, (hipStream_t)0);
+    return temp;
+}
+
+size_t nm_sort_pairs_temp_bytes(int64_t n)
+{
+    size_t temp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                                    (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 64,
+                                    (hipStream_t)0);
+    return temp;
+}
+
+extern "C" size_t nm_voxelize_workspace_bytes(int64_t n)
+{
+    if (n < 1) n = 1;
+    int64_t tiles = (n + UNIQ_TILE - 1) / UNIQ_TILE;
+    return align_up((size_t)n * 8) * 2 + align_up(sort_keys_temp_bytes(n)) +
+           align_up((size_t)tiles * 4) + 256;
+}
+
+extern "C" int nm_voxelize(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                           const nm_lattice* lat, int64_t* d_addr_out, int64_t* d_count,
+                           void* d_work, size_t work_bytes, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (!d_xyz || !d_addr_out || !d_count || !d_work || n < 1 || stride < 3 ||
+        n >= (int64_t)1 << 31)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_voxelize: bad arguments");
+    int rc = validate_lattice(ctx, lat);
+    if (rc) return rc;
+    if (work_bytes < nm_voxelize_workspace_bytes(n))
+        NM_FAIL(ctx, NM_ERR_WORKSPACE, "nm_voxelize: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    LatticeDev L = make_lattice_dev(lat);
+    char* w = (char*)d_work;
+    uint64_t* addr = (uint64_t*)w;           w += align_up((size_t)n * 8);
+    uint64_t* sorted = (uint64_t*)w;         w += align_up((size_t)n * 8);
+    size_t temp_bytes = sort_keys_temp_bytes(n);
+    void* temp = w;                          w += align_up(temp_bytes);
+    int64_t tiles = (n + UNIQ_TILE - 1) / UNIQ_TILE;
+    uint32_t* tile_count = (uint32_t*)w;
+
+    NM_HIP(ctx, hipMemsetAsync(d_count, 0, 2 * sizeof(int64_t), s));
+    k_addresses<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, addr, d_count + 1);
+    unsigned end_bit = (unsigned)(L.wx + L.wy + L.wz);
+    NM_HIP(ctx, rocprim::radix_sort_keys(temp, temp_bytes, addr, sorted, (size_t)n, 0, end_bit, s));
+    k_unique_count<<<(int)tiles, UNIQ_BLOCK, 0, s>>>(sorted, n, tile_count);
+    k_tile_prefix<<<1, 1024, 0, s>>>(tile_count, tiles, d_count);
+    k_unique_write<<<(int)tiles, UNIQ_BLOCK, 0, s>>>(sorted, n, tile_count, d_addr_out);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+__global__ __launch_bounds__(256) void k_addr_to_coord(const int64_t* __restrict__ addr, int64_t m,
+                                                       LatticeDev L, double* __restrict__ out)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint64_t a = (uint64_t)addr[i];
+    // masks of geometry.py:74-79, shifts back of :131-132
+    int32_t cx = (int32_t)(a & ((1ull << L.wx) - 1ull));
+    int32_t cy = (int32_t)((a >> L.s0) & ((1ull << L.wy) - 1ull));
+    int32_t cz = (int32_t)((a >> L.s1) & ((1ull << L.wz) - 1ull));
+    out[i * 3 + 0] = nm_centre(cx, L.min_x, L.edge, L.half_edge);
+    out[i * 3 + 1] = nm_centre(cy, L.min_y, L.edge, L.half_edge);
+    out[i * 3 + 2] = nm_centre(cz, L.min_z, L.edge, L.half_edge);
+}
+
+extern "C" int nm_address_to_coordinate(nm_ctx* ctx, const int64_t* d_addr, int64_t m,
+                                        const nm_lattice* lat, double* d_xyz_out, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (m < 0 || (m > 0 && (!d_addr || !d_xyz_out)))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_address_to_coordinate: bad arguments");
+    int rc = validate_lattice(ctx, lat);
+    if (rc) return rc;
+    if (m == 0) return NM_OK;
+    LatticeDev L = make_lattice_dev(lat);
+    k_addr_to_coord<<<(int)((m + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_addr, m, L,
+                                                                             d_xyz_out);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the per-scale occupancy index
+// ---------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_cell_keys(const double* __restrict__ xyz, int64_t n,
+                                                   int64_t stride, LatticeDev L,
+                                                   uint64_t* __restrict__ key,
+                                                   uint32_t* __restrict__ val)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = xyz + i * stride;
+    int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
+    int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
+    int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
+    // points outside the lattice (a query cloud that is not the search cloud) are clamped for
+    // ordering only; the search kernel recomputes their true cell.
+    cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
+    cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
+    cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
+    key[i] = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
+    val[i] = (uint32_t)i;
+}
+
+// pass A: the first key of every superblock allocates a leaf, zeroes it and publishes key -> leaf in
+// the hash table.  one atomicAdd per block on the leaf counter.
+__global__ __launch_bounds__(256) void k_index_leaves(const uint64_t* __restrict__ skey, int64_t n,
+                                                      IndexDev I)
+{
+    __shared__ uint32_t wcount[4];
+    __shared__ uint32_t block_base;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool head = false;
+    uint64_t sb = 0;
+    if (i < n) {
+        sb = skey[i] >> NM_LOCAL_BITS;
+        head = (i == 0) || ((skey[i - 1] >> NM_LOCAL_BITS) != sb);
+    }
+    unsigned long long m = __ballot(head);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wcount[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        block_base = t ? atomicAdd(&I.counters[0], t) : 0u;
+    }
+    __syncthreads();
+    if (!head) return;
+    uint32_t idx = block_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (int ww = 0; ww < w; ++ww) idx += wcount[ww];
+    if (idx >= I.leaf_capacity) {
+        I.counters[2] = 1u;   // cannot happen when the workspace was sized by the library
+        return;
+    }
+    uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
+#pragma unroll
+    for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t slot = nm_hash64(sb) & I.hash_mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&I.hash_key[slot],
+                                            (unsigned long long)NM_HASH_EMPTY,
+                                            (unsigned long long)sb);
+        if (prev == NM_HASH_EMPTY) {
+            I.hash_val[slot] = idx;
+            break;
+        }
+        slot = (slot + 1) & I.hash_mask;
+    }
+}
+
+// pass B: the first key of every distinct cell sets its bit in the leaf; M is counted on the way.
+__global__ __launch_bounds__(256) void k_index_bits(const uint64_t* __restrict__ skey, int64_t n,
+                                                    IndexDev I)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool head = false;
+    uint64_t k = 0;
+    if (i < n) {
+        k = skey[i];
+        head = (i == 0) || (skey[i - 1] != k);
+    }
+    if (head) {
+        int32_t leaf = nm_hash_find(I, k >> NM_LOCAL_BITS);
+        if (leaf >= 0) {
+            uint32_t local = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
+            atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)],
+                     1u << (local & 31u));
+        }
+    }
+    unsigned long long m = __ballot(head);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(&I.counters[1], (uint32_t)__popcll(m));
+}
+
+static uint64_t lattice_superblocks(const LatticeDev& L)
+{
+    // bx+by+bz <= 64 - 11, so this fits
+    return 1ull << (L.bx + L.by + L.bz);
+}
+
+void nm_index_layout(const LatticeDev& L, int64_t n_search, IndexLayout* out)
+{
+    uint64_t cap = lattice_superblocks(L);
+    if (cap > (uint64_t)n_search) cap = (uint64_t)n_search;
+    if (cap < 1) cap = 1;
+    uint64_t hcap = 64;
+    while (hcap < cap * 2) hcap <<= 1;
+    out->leaf_capacity = (uint32_t)cap;
+    out->hash_capacity = (uint32_t)hcap;
+    out->hash_key_bytes = align_up((size_t)hcap * 8);
+    out->hash_val_bytes = align_up((size_t)hcap * 4);
+    out->leaf_bytes = align_up((size_t)cap * NM_LEAF_WORDS * 4);
+    out->counter_bytes = 256;
+    out->total = out->hash_key_bytes + out->hash_val_bytes + out->leaf_bytes + out->counter_bytes;
+}
+
+int nm_sort_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const LatticeDev& L,
+                  uint64_t* key_tmp, uint32_t* val_tmp, uint64_t* key_sorted, uint32_t* val_sorted,
+                  void* sort_temp, size_t sort_temp_bytes, hipStream_t s)
+{
+    k_cell_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, key_tmp, val_tmp);
+    NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp,
+                                          val_sorted, (size_t)n, 0, (unsigned)L.keybits, s));
+    return NM_OK;
+}
+
+int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const IndexLayout& lay,
+                   void* index_mem, IndexDev* out, hipStream_t s)
+{
+    char* w = (char*)index_mem;
+    IndexDev I;
+    I.hash_key = (uint64_t*)w;      w += lay.hash_key_bytes;
+    I.hash_val = (uint32_t*)w;      w += lay.hash_val_bytes;
+    I.leaf = (uint32_t*)w;          w += lay.leaf_bytes;
+    I.counters = (uint32_t*)w;
+    I.hash_mask = lay.hash_capacity - 1;
+    I.leaf_capacity = lay.leaf_capacity;
+    NM_HIP(ctx, hipMemsetAsync(I.hash_key, 0xFF, (size_t)lay.hash_capacity * 8, s));
+    NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
+    int blocks = (int)((n + 255) / 256);
+    k_index_leaves<<<blocks, 256, 0, s>>>(key_sorted, n, I);
+    k_index_bits<<<blocks, 256, 0, s>>>(key_sorted, n, I);
+    NM_HIP(ctx, hipGetLastError());
+    *out = I;
+    return NM_OK;
+}

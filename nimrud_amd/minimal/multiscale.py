@@ -1,0 +1,175 @@
+"""
+multiscale operator processing pipeline on the MI355X: the drop-in for nimrud/minimal/multiscale.py.
+
+features are generated for points in the query cloud, using geometry from the search cloud.  for each
+scale: voxel-filter the search cloud at `edge_length`, find every occupied voxel centre within
+`radius` of each query point, and emit [population, distance to the neighborhood centroid, largest
+and middle eigenvalue of the covariance normalised by the eigenvalue sum] (multiscale.py:1-6,70-123).
+undefined features (neighborhoods of fewer than two voxels) are zeros, as the reference documents
+(multiscale.py:4-5); pass strict=True to get the FloatingPointError the reference actually raises
+from numpy.cov in that case.
+
+same names and signatures as the reference:
+    process_single_core(query_cloud, search_cloud, edge_lengths, radii, verbose=False)  -> (Nq, 4*S)
+    one_scale_single_core(query_cloud, search_cloud, edge_length, radius, verbose=False) -> (Nq, 4)
+("single core" is kept for compatibility: the work runs on one GPU.)  additive, for data that already
+lives in HBM: process_gpu / one_scale_gpu take and return torch GPU tensors.
+
+each scale is one call into libnimrud_hip.so (nm_scale_features): cell keys -> radix sort -> sparse
+occupancy index -> fused search/moments/eigen kernel.  see DESIGN.md.
+"""
+
+import ctypes
+import time
+
+import numpy as np
+import torch
+
+from nimrud_amd import device as _device
+from nimrud_amd.utils import geometry
+
+# kept for API compatibility with the reference (multiscale.py:18-24).  the GPU path has no kd-tree
+# and no host-side chunk loop, so LEAFSIZE and QUERY_CHUNK_SIZE have no effect here.
+LEAFSIZE = 300
+QUERY_CHUNK_SIZE = 1000
+VERBOSITY_INTERVAL = 100
+
+
+class ScaleInfo(object):
+    """what one scale reported: voxels = M (occupied search voxels), degenerate = neighborhoods with
+    population < 2, extra_passes = search-kernel passes beyond one per wave, leaves = index leaves."""
+
+    def __init__(self, values):
+        self.voxels, self.degenerate, self.extra_passes, self.leaves = (int(v) for v in values)
+
+    def __repr__(self):
+        return "ScaleInfo(voxels=%d, degenerate=%d, extra_passes=%d, leaves=%d)" % (
+            self.voxels, self.degenerate, self.extra_passes, self.leaves)
+
+
+def _scale_into(rt, query, search, shared, lo, hi, edge_length, radius, out_view, info_view):
+    """enqueue one scale: features of `query` against `search` into out_view (Nq,4 strided)."""
+    vf = geometry.VoxelFilter.from_bounds(lo, hi, edge_length, device=rt.device)
+    lat = vf.nm_lattice
+    nq, ns = query.shape[0], search.shape[0]
+    nbytes = rt.lib.nm_scale_workspace_bytes(nq, ns, ctypes.byref(lat))
+    work = rt.workspace(nbytes)
+    qt = search if shared else query
+    rt.check(rt.lib.nm_scale_features(
+        rt.ctx, _device.ptr(qt), nq, _device.row_stride(qt),
+        _device.ptr(search), ns, _device.row_stride(search),
+        ctypes.byref(lat), float(radius),
+        _device.ptr(out_view), int(out_view.stride(0)), _device.ptr(info_view),
+        _device.ptr(work), work.numel(), rt.stream()))
+
+
+def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, strict=False,
+                return_info=False, out=None):
+    """process_single_core for clouds resident in HBM: torch GPU tensors in, (Nq, 4*S) fp64 GPU tensor
+    out.  nothing crosses PCIe except six doubles (the search cloud's extrema) and, when strict or
+    return_info, 4 counters per scale."""
+    assert len(edge_lengths) == len(radii), \
+        "edge_lengths and radii should be equal-length sequences."
+    shared = query_cloud is search_cloud
+    rt, search = _device.as_cloud(search_cloud)
+    query = search if shared else _device.as_cloud(query_cloud, rt.device)[1]
+    if search.shape[1] < 3 or query.shape[1] < 3:
+        raise ValueError("only 3D spaces supported by the multiscale pipeline")
+    if search.shape[0] < 2:
+        raise ValueError("need at least 2 points to define a voxel grid")
+    n_scales = len(edge_lengths)
+    nq = query.shape[0]
+    if out is None:
+        out = torch.empty((nq, 4 * n_scales), dtype=torch.float64, device=rt.device)
+    info = torch.zeros((max(n_scales, 1), 4), dtype=torch.int64, device=rt.device)
+    if n_scales == 0:
+        return (out, []) if return_info else out
+
+    outer_start = time.perf_counter()
+    lo, hi = _device.cloud_bounds(rt, search)
+    for s, (this_edge, this_radius) in enumerate(zip(edge_lengths, radii)):
+        inner_start = time.perf_counter()
+        _scale_into(rt, query, search, shared, lo, hi, this_edge, this_radius,
+                    out[:, 4 * s:4 * s + 4], info[s])
+        if verbose:
+            torch.cuda.synchronize(rt.device)
+            inner = time.perf_counter() - inner_start
+            print("querying {} points against a search space of {} voxels".format(
+                nq, int(info[s, 0])))
+            print("using a voxel edge length of {} and radius of {}".format(this_edge, this_radius))
+            print("this scale took {}s".format(np.around(inner, 6)))
+            print("one scale rate of {} points per second".format(np.around(nq / inner, 3)))
+            print("===================================")
+    if verbose:
+        torch.cuda.synchronize(rt.device)
+        outer = time.perf_counter() - outer_start
+        print("calculating all scales took {}s".format(np.around(outer, 6)))
+        print("final rate of {} points per second".format(np.around(nq / outer, 3)))
+
+    if strict or return_info:
+        host = info.cpu().numpy()
+        if strict and host[:n_scales, 1].any():
+            raise FloatingPointError(
+                "%d neighborhoods have fewer than 2 voxels; their covariance is undefined "
+                "(the reference raises here from numpy.cov, features.py:43)"
+                % int(host[:n_scales, 1].sum()))
+        if return_info:
+            return out, [ScaleInfo(row) for row in host[:n_scales]]
+    return out
+
+
+def one_scale_gpu(query_cloud, search_cloud, edge_length, radius, verbose=False, strict=False):
+    """(Nq,4) GPU tensor for one analysis scale."""
+    return process_gpu(query_cloud, search_cloud, [edge_length], [radius], verbose=verbose,
+                       strict=strict)
+
+
+def process_single_core(query_cloud, search_cloud, edge_lengths, radii, verbose=False, strict=False):
+    """compute features at multiple scales.  returns an array of feature vectors aligned with the
+    query cloud: numpy (Nq, 4*S) fp64, scale blocks in caller order (multiscale.py:27-67)."""
+    assert len(edge_lengths) == len(radii), \
+        "edge_lengths and radii should be equal-length sequences."
+    shared = query_cloud is search_cloud
+    rt, search = _device.as_cloud(search_cloud)
+    query = search if shared else _device.as_cloud(query_cloud, rt.device)[1]
+    result = process_gpu(query, search, edge_lengths, radii, verbose=verbose, strict=strict)
+    return result.cpu().numpy()
+
+
+def one_scale_single_core(query_cloud, search_cloud, edge_length, radius, verbose=False,
+                          strict=False):
+    """generate a 4d feature vector representing one analysis scale (multiscale.py:70-123)."""
+    return process_single_core(query_cloud, search_cloud, [edge_length], [radius], verbose=verbose,
+                               strict=strict)
+
+
+def neighbor_lists(query_cloud, search_cloud, edge_length, radius):
+    """the neighbor index lists of multiscale.py:103 as CSR (offsets int64[Nq+1], index int64[total]):
+    for every query point the ascending positions, in the sorted unique voxel array of
+    VoxelFilter.unique_voxels(search_cloud), of the voxels within `radius`.  inspection / parity mode:
+    it searches by address and is much slower than the fused feature path."""
+    shared = query_cloud is search_cloud
+    as_torch = isinstance(query_cloud, torch.Tensor)
+    rt, search = _device.as_cloud(search_cloud)
+    query = search if shared else _device.as_cloud(query_cloud, rt.device)[1]
+    vf = geometry.VoxelFilter(search[:, :3], edge_length, device=rt.device)
+    addr = vf.unique_addresses(search[:, :3])
+    nq = query.shape[0]
+    counts = torch.empty(nq, dtype=torch.int32, device=rt.device)
+    lat = vf.nm_lattice
+    null = ctypes.c_void_p(0)
+    rt.check(rt.lib.nm_scale_neighbors(rt.ctx, _device.ptr(query), nq, _device.row_stride(query),
+                                       _device.ptr(addr), addr.shape[0], ctypes.byref(lat),
+                                       float(radius), _device.ptr(counts), null, null, rt.stream()))
+    offsets = torch.zeros(nq + 1, dtype=torch.int64, device=rt.device)
+    torch.cumsum(counts, 0, out=offsets[1:])
+    total = int(offsets[-1])
+    index = torch.empty(max(total, 1), dtype=torch.int64, device=rt.device)
+    rt.check(rt.lib.nm_scale_neighbors(rt.ctx, _device.ptr(query), nq, _device.row_stride(query),
+                                       _device.ptr(addr), addr.shape[0], ctypes.byref(lat),
+                                       float(radius), null, _device.ptr(offsets), _device.ptr(index),
+                                       rt.stream()))
+    index = index[:total]
+    if as_torch:
+        return offsets, index
+    return offsets.cpu().numpy(), index.cpu().numpy()

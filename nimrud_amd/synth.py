@@ -90,11 +90,12 @@ CONFIGS = {
 }
 
 
-def make_config(name, n=None):
+def make_config(name, n=None, seed_offset=0):
     """returns (points, labels_or_None, edges, radii) for a named configuration; `n` overrides the
     point count (same generator, same density when the extent is scaled by the caller)."""
     cfg = dict(CONFIGS[name])
-    if n is not None:
+    cfg["seed"] = cfg["seed"] + 1000 * seed_offset
+    if n is not None and n != cfg["n"]:
         # keep the areal density: scale the extent with sqrt(n)
         cfg["extent"] = cfg["extent"] * np.sqrt(n / cfg["n"]) if cfg["kind"] == "scene" \
             else cfg["extent"] * (n / cfg["n"]) ** (1.0 / 3.0)

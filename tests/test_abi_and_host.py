@@ -1,0 +1,134 @@
+"""
+CPU tests (no GPU): the C-ABI library loads and exports every symbol include/nimrud_hip.h declares,
+the ctypes table matches the header, and the host-side logic (lattice parameters, batcher, synthetic
+clouds, forest flattening, the loud failure without a GPU) behaves.
+"""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from nimrud_amd import _ffi, synth
+from nimrud_amd.utils import generic, geometry
+from oracle import nimrud_oracle as oracle
+
+HEADER = os.path.join(REPO, "include", "nimrud_hip.h")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(nm_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_ffi.LIBRARY_PATH)
+    names = header_functions()
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(lib, name), "libnimrud_hip.so does not export %s" % name
+
+
+def test_binding_table_matches_header():
+    assert sorted(_ffi.SIGNATURES) == header_functions()
+    lib = _ffi.load()
+    assert lib.nm_abi_version() == _ffi.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    # struct nm_lattice {double[3]; double; int32[3]; int32[2]} -> 32 + 20 (+4 pad) = 56 bytes
+    assert ctypes.sizeof(_ffi.NmLattice) == 56
+    assert _ffi.NmLattice.edge.offset == 24 and _ffi.NmLattice.widths.offset == 32
+    assert _ffi.NmLattice.shifts.offset == 44
+    assert ctypes.sizeof(_ffi.NmForest) == 6 * 8 + 4 * 4
+
+
+def test_workspace_queries_need_no_gpu():
+    lib = _ffi.load()
+    lat = geometry.make_nm_lattice([0.0, 0.0, 0.0], 0.1, [10, 10, 6])
+    small = lib.nm_scale_workspace_bytes(1000, 1000, ctypes.byref(lat))
+    big = lib.nm_scale_workspace_bytes(100000, 100000, ctypes.byref(lat))
+    assert 0 < small < big
+    assert lib.nm_voxelize_workspace_bytes(1000) < lib.nm_voxelize_workspace_bytes(1000000)
+
+
+def test_no_gpu_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from nimrud_amd.minimal import multiscale
+    pts = synth.uniform_cloud(100)
+    with pytest.raises(RuntimeError):
+        multiscale.process_single_core(pts, pts, [0.25], [0.75])
+    with pytest.raises(RuntimeError):
+        geometry.VoxelFilter(pts, 0.25)
+
+
+def test_length_mismatch_is_assertion_error():
+    # multiscale.py:32-33
+    from nimrud_amd.minimal import multiscale
+    pts = synth.uniform_cloud(100)
+    with pytest.raises(AssertionError):
+        multiscale.process_single_core(pts, pts, [0.25, 0.5], [0.75])
+
+
+@pytest.mark.parametrize("name", ["g1_uniform.npz", "g2_scene.npz", "g3_offset.npz"])
+def test_lattice_parameters_match_reference(golden, name):
+    g = golden(name)
+    pts = g["points"]
+    for s, e in enumerate(g["edges"]):
+        mc, xc, widths, shifts = geometry.lattice_parameters(pts.min(0), pts.max(0), e)
+        assert np.array_equal(mc, g["s%d_min_corner" % s])
+        assert np.array_equal(widths, g["s%d_widths" % s])
+        assert np.array_equal(shifts, g["s%d_shifts" % s])
+        lat = oracle.Lattice(pts, e)
+        assert np.array_equal(xc, lat.maximum_corner)
+
+
+def test_lattice_parameters_known_answers():
+    # geometry_tests.py:84-138
+    mc, xc, widths, shifts = geometry.lattice_parameters([0, 0, 0], [100, 100, 100], 0.001)
+    assert list(widths) == [17, 17, 17] and list(shifts) == [17, 34]
+    with pytest.raises(ValueError):
+        geometry.lattice_parameters([0, 0, 0], [100, 100, 100], 0.00001)
+    with pytest.raises(ValueError):
+        geometry.lattice_parameters([0, 0], [100, 100], 0.00000001)
+
+
+def test_batcher():
+    # generic.py:8-26
+    arr = np.arange(10)
+    assert [list(c) for c in generic.batcher(arr, 4)] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+    assert list(generic.batcher([1, 2, 3], 2)) == [[1, 2], [3]]
+    assert list(generic.batcher(iter(range(5)), 2)) == [[0, 1], [2, 3], [4]]
+    assert list(generic.batcher(iter(()), 2)) == []
+
+
+def test_synthetic_clouds_are_deterministic_and_fp32_representable():
+    a, la = synth.scene_cloud(5000, extent=5.0, n_poles=3, n_spheres=2, seed=3)
+    b, lb = synth.scene_cloud(5000, extent=5.0, n_poles=3, n_spheres=2, seed=3)
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
+    assert np.array_equal(a, a.astype(np.float32).astype(np.float64))
+    assert set(np.unique(la)) == {0, 1, 2}
+    pts, _, edges, radii = synth.make_config("c1_uniform_100k", n=1000)
+    assert pts.shape == (1000, 3) and edges == [0.25] and radii == [0.75]
+    order = synth.morton_sort(a, 0.8)
+    assert sorted(order) == list(range(len(a)))
+
+
+def test_forest_flattening_matches_sklearn(golden):
+    from sklearn.ensemble import RandomForestClassifier
+    from nimrud_amd.minimal.classification import ForestModel
+    rs = np.random.RandomState(0)
+    x = rs.rand(400, 6)
+    y = (x[:, 0] + x[:, 3] > 1).astype(int) + (x[:, 5] > 0.8)
+    clf = RandomForestClassifier(n_estimators=5, max_depth=6, random_state=0).fit(x, y)
+    model = ForestModel.flatten_sklearn(clf)
+    xe = rs.rand(300, 6)
+    assert np.abs(oracle.forest_predict_proba(model, xe) - clf.predict_proba(xe)).max() < 1e-15
+    assert np.array_equal(oracle.forest_predict(model, xe), clf.predict(xe))

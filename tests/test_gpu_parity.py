@@ -1,0 +1,279 @@
+"""
+GPU parity tests (run with `-m gpu` on an MI355X).  everything goes through the C ABI
+(libnimrud_hip.so via nimrud_amd); the oracle and the golden vectors are only the checker.
+
+bar: population and neighbor indices bit-exact; eigen-features |a-b| <= 1e-5*|b| + 1e-9; centroid
+distance 1e-9 relative plus the fp64 representation error of the coordinates (conftest.py).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_features_close
+from nimrud_amd import synth
+from nimrud_amd.minimal import classification, features, multiscale
+from nimrud_amd.utils import geometry
+from oracle import nimrud_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+PIPELINE_FIXTURES = ["g1_uniform.npz", "g2_scene.npz", "g3_offset.npz", "g4_lattice.npz"]
+
+
+# ---- the reference's own VoxelFilter tests, against the GPU VoxelFilter ---------------------------
+
+def test_voxel_init():
+    # geometry_tests.py:17-80
+    rs = np.random.RandomState(10)
+    for dim in (2, 3):
+        with pytest.raises(ValueError):
+            geometry.VoxelFilter(rs.rand(1, dim) * 100, 0.5)
+        pts = rs.rand(1000, dim) * 100
+        vf = geometry.VoxelFilter(pts, 0.5)
+        assert np.array_equal(vf.minimum_corner, pts.min(0) - 0.25)
+        assert np.array_equal(vf.maximum_corner, pts.max(0) + 0.25)
+        assert vf.edge_length == 0.5
+    for dim in (1, 4):
+        with pytest.raises(ValueError):
+            geometry.VoxelFilter(rs.rand(1000, dim) * 100, 0.5)
+    with pytest.raises(ValueError):
+        geometry.VoxelFilter(rs.rand(10), 0.5)
+    with pytest.raises(ValueError):
+        geometry.VoxelFilter(rs.rand(10, 10, 10), 0.5)
+
+
+def test_voxel_shift_masks_bounds():
+    # geometry_tests.py:84-192
+    for dim in (2, 3):
+        pts = np.asarray([[0, 0, 0], [100, 100, 100]])[:, :dim]
+        vf = geometry.VoxelFilter(pts, 0.001)
+        assert np.array_equal(vf.shifts, [17, 34][:dim - 1])
+        assert np.array_equal(vf.widths, [17, 17, 17][:dim])
+        with pytest.raises(ValueError):
+            geometry.VoxelFilter(pts, 0.00001 if dim == 3 else 0.00000001)
+        vf = geometry.VoxelFilter(pts, 1)
+        assert np.array_equal(vf.masks, [0b1111111, 0b11111110000000, 0b111111100000000000000][:dim])
+
+        def ok(p):
+            try:
+                vf._check_in_bounds(p)
+            except ValueError:
+                return False
+            return True
+        assert ok(np.zeros((1, dim)) - 0.5)
+        assert not ok(np.zeros((1, dim)) - 1.5)
+        assert ok(np.zeros((1, dim)) + 0.5)
+        assert ok(np.zeros((1, dim)) + 100.5)
+        assert not ok(np.zeros((1, dim)) + 101.5)
+        assert not ok(np.zeros((1, dim + 1)))
+        assert ok(np.zeros(dim))
+        assert not ok(np.zeros(dim + 1))
+
+
+def test_voxel_address_transform_unique():
+    # geometry_tests.py:196-279
+    vf = geometry.VoxelFilter(np.asarray([[0, 0, 0], [100, 100, 100]]), 1)
+    assert vf.coordinate_to_address(np.arange(3) + 10)[0] == 198026
+    assert np.allclose(vf.address_to_coordinate(198026).flatten(), np.arange(3) + 10)
+    vf2 = geometry.VoxelFilter(np.asarray([[0, 0], [100, 100]]), 1)
+    assert np.allclose(vf2.address_to_coordinate(vf2.coordinate_to_address([10, 11]).flatten()),
+                       [[10, 11]])
+    for dim in (2, 3):
+        vf = geometry.VoxelFilter(np.asarray([[0, 0, 0], [100, 100, 100]])[:, :dim], 1)
+        pts = np.concatenate([np.zeros((1, dim)) + off for off in np.arange(0, 20, 2)])
+        assert np.array_equal(vf.unique_voxels(np.vstack((pts, pts))), pts)
+
+
+# ---- golden vectors captured from the reference ----------------------------------------------------
+
+@pytest.mark.parametrize("name", PIPELINE_FIXTURES)
+def test_golden_addresses_and_centres(golden, name):
+    g = golden(name)
+    pts = g["points"]
+    for s, e in enumerate(g["edges"]):
+        vf = geometry.VoxelFilter(pts, e)
+        assert np.array_equal(vf.minimum_corner, g["s%d_min_corner" % s])
+        assert np.array_equal(vf.unique_addresses(pts), g["s%d_addresses" % s])
+        lat = oracle.Lattice(pts, e)
+        assert np.array_equal(vf.coordinate_to_address(pts), lat.coordinate_to_address(pts))
+        # centres must be bit-identical to the reference's (they feed the inclusion test)
+        assert np.array_equal(vf.unique_voxels(pts), lat.unique_voxels(pts))
+
+
+@pytest.mark.parametrize("name", PIPELINE_FIXTURES)
+def test_golden_features(golden, name):
+    g = golden(name)
+    pts = g["points"]
+    got = multiscale.process_single_core(pts, pts, list(g["edges"]), list(g["radii"]))
+    assert_features_close(got, g["features"], pts)
+
+
+@pytest.mark.parametrize("name", PIPELINE_FIXTURES)
+def test_golden_neighbor_indices_bit_exact(golden, name):
+    g = golden(name)
+    pts = g["points"]
+    for s, (e, r) in enumerate(zip(g["edges"], g["radii"])):
+        want_off, want_idx = g["s%d_nbr_offsets" % s], g["s%d_nbr_index" % s]
+        n = len(want_off) - 1
+        off, idx = multiscale.neighbor_lists(pts[:n], pts, e, r)
+        assert np.array_equal(off, want_off)
+        assert np.array_equal(idx, want_idx)
+
+
+def test_golden_operators(golden):
+    g = golden("g4_operators.npz")
+    q = g["query"]
+    for key in ("two", "three_collinear", "three", "four_coplanar", "plane_lattice", "line_lattice",
+                "blob"):
+        nb = g[key + "_points"]
+        assert features.population(nb) == g[key + "_population"]
+        assert abs(features.centroid(q, nb) - g[key + "_centroid"]) <= 1e-12
+        want = g[key + "_pca"]
+        assert np.all(np.abs(features.pca(nb) - want) <= 1e-5 * np.abs(want) + 1e-9)
+    for key, nb in (("empty", np.zeros((0, 3))), ("one", np.array([[1.0, 2.0, 3.0]]))):
+        assert features.population(nb) == g[key + "_population"]
+        assert abs(features.centroid(q, nb) - g[key + "_centroid"]) <= 1e-12
+        assert np.array_equal(features.pca(nb), np.zeros(2))
+        with pytest.raises(FloatingPointError):
+            features.pca(nb, strict=True)
+    idx = np.array([3, 1, 2])
+    assert np.array_equal(features.take(idx, g["blob_points"]), g["blob_points"][idx])
+
+
+def test_golden_forest(golden):
+    g = golden("g5_forest.npz")
+    model = classification.ForestModel.from_arrays(g)
+    proba = model.predict_proba(g["x"])
+    assert np.abs(proba - g["proba"]).max() <= 1e-15
+    assert np.array_equal(model.predict(g["x"]), g["label"])
+
+
+# ---- seeded clouds against the oracle ---------------------------------------------------------------
+
+@pytest.mark.parametrize("ratio", [0.9, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0, 5.2])
+def test_oracle_radius_ratios(ratio):
+    # exercises every kernel variant: W = 3, 5, 7, 9 (LUT kernels) and W = 11 (generic kernel)
+    pts = synth.uniform_cloud(6000, extent=4.0, seed=11)
+    e = 0.2
+    got = multiscale.process_single_core(pts, pts, [e], [ratio * e])
+    want = oracle.process_fast(pts, pts, [e], [ratio * e])
+    assert_features_close(got, want, pts)
+
+
+def test_oracle_scene_three_scales():
+    pts, _ = synth.scene_cloud(60000, extent=15.0, n_poles=12, n_spheres=3, seed=21)
+    edges, radii = [0.10, 0.20, 0.40], [0.30, 0.60, 1.20]
+    got, info = multiscale.process_gpu(torch.from_numpy(pts).cuda(), None or torch.from_numpy(pts).cuda(),
+                                       edges, radii, return_info=True)
+    want = oracle.process_fast(pts, pts, edges, radii)
+    assert_features_close(got.cpu().numpy(), want, pts)
+    for s, e in enumerate(edges):
+        assert info[s].voxels == len(oracle.Lattice(pts, e).unique_addresses(pts))
+        assert info[s].degenerate == int((want[:, 4 * s] < 2).sum())
+
+
+def test_oracle_separate_query_cloud_partly_outside():
+    search = synth.uniform_cloud(8000, extent=3.0, seed=31)
+    rs = np.random.RandomState(32)
+    query = rs.rand(3000, 3) * 5.0 - 1.0          # a third of them far outside the lattice
+    query[:5] = [[-100.0, 0, 0], [0, 1e6, 0], [1.5, 1.5, -50.0], [1e9, 1e9, 1e9], [-3.0, -3.0, -3.0]]
+    e, r = 0.25, 0.75
+    got = multiscale.process_single_core(query, search, [e], [r])
+    want = oracle.process_fast(query, search, [e], [r])
+    assert (want[:, 0] == 0).sum() > 100 and (want[:, 0] == 1).sum() > 0
+    assert_features_close(got, want, np.concatenate((query[5:], search)))
+
+
+def test_oracle_sparse_cloud_many_passes():
+    # isolated points far apart: every wave needs many passes of the search kernel
+    rs = np.random.RandomState(41)
+    pts = rs.rand(2000, 3) * 400.0
+    pts = np.concatenate((pts, pts[:500] + 0.05), axis=0)
+    e, r = 0.1, 0.3
+    got, info = multiscale.process_gpu(torch.from_numpy(pts).cuda(), torch.from_numpy(pts).cuda(),
+                                       [e], [r], return_info=True)
+    want = oracle.process_fast(pts, pts, [e], [r])
+    assert_features_close(got.cpu().numpy(), want, pts)
+    assert info[0].extra_passes > 0
+
+
+def test_strided_cloud_with_feature_columns():
+    # (N, 3+F) clouds: geometry in the first three columns (minimal/README.md:38-40)
+    pts = synth.uniform_cloud(5000, extent=3.0, seed=51)
+    wide = np.concatenate((pts, np.random.RandomState(52).rand(5000, 4)), axis=1)
+    a = multiscale.process_single_core(wide, wide, [0.2], [0.6])
+    b = multiscale.process_single_core(pts, pts, [0.2], [0.6])
+    assert np.array_equal(a, b)
+
+
+def test_strict_raises_like_the_reference():
+    pts = np.concatenate((synth.uniform_cloud(500, extent=1.0, seed=61), [[50.0, 50.0, 50.0]]))
+    out = multiscale.process_single_core(pts, pts, [0.1], [0.3])
+    assert out[-1, 0] == 1 and out[-1, 2] == 0 and out[-1, 3] == 0
+    with pytest.raises(FloatingPointError):
+        multiscale.process_single_core(pts, pts, [0.1], [0.3], strict=True)
+
+
+def test_neighbor_lists_against_oracle():
+    pts, _ = synth.scene_cloud(20000, extent=8.0, n_poles=5, n_spheres=2, seed=71)
+    e, r = 0.1, 0.3
+    off, idx = multiscale.neighbor_lists(pts[:3000], pts, e, r)
+    voxels = oracle.Lattice(pts, e).unique_voxels(pts)
+    want_off, want_idx = oracle.neighbors_to_csr(oracle.ball_neighbors_kdtree(pts[:3000], voxels, r))
+    assert np.array_equal(off, want_off)
+    assert np.array_equal(idx, want_idx)
+    # and the fused path's population is the length of those lists
+    feats = multiscale.process_single_core(pts[:3000], pts, [e], [r])
+    assert np.array_equal(feats[:, 0], np.diff(off))
+
+
+def test_forest_on_gpu_features():
+    from sklearn.ensemble import RandomForestClassifier
+    pts, labels = synth.scene_cloud(30000, extent=10.0, n_poles=8, n_spheres=3, seed=81)
+    feats = multiscale.process_single_core(pts, pts, [0.1, 0.2], [0.3, 0.6])
+    clf = RandomForestClassifier(n_estimators=12, max_depth=9, random_state=0).fit(
+        feats[:20000], labels[:20000])
+    model = classification.ForestModel.from_sklearn(clf)
+    assert np.abs(model.predict_proba(feats[20000:]) - clf.predict_proba(feats[20000:])).max() < 1e-14
+    assert np.array_equal(model.predict(feats[20000:]), clf.predict(feats[20000:]))
+
+
+# ---- BASELINE configurations at full size: size-independent properties ----------------------------
+
+def test_config1_full_size_checksum_against_oracle():
+    # config 1: 100k uniform points, one scale - small enough for the vectorised oracle
+    pts, _, edges, radii = synth.make_config("c1_uniform_100k")
+    got = multiscale.process_single_core(pts, pts, edges, radii)
+    want = oracle.process_fast(pts, pts, edges, radii)
+    assert_features_close(got, want, pts)
+    assert len(oracle.Lattice(pts, edges[0]).unique_addresses(pts)) == 51997
+
+
+def test_config2_full_size_properties():
+    # config 2: 1M-point scene, 3 scales.  properties that need no oracle at this size:
+    #  (a) permutation equivariance: shuffling the rows shuffles the output rows, bit for bit
+    #  (b) query-subset consistency: a query subset against the same search cloud gives the same rows
+    #  (c) ranges: population in [1, W^3], 1 >= l1 >= l2 >= 0, l1 + l2 <= 1, l1 >= 1/3
+    #  (d) a 20k-row sample agrees with the oracle
+    pts, _, edges, radii = synth.make_config("c2_scene_1m")
+    dev = torch.from_numpy(pts).cuda()
+    full = multiscale.process_gpu(dev, dev, edges, radii)
+    perm = torch.randperm(len(pts), generator=torch.Generator().manual_seed(5)).cuda()
+    shuffled = dev[perm].contiguous()
+    again = multiscale.process_gpu(shuffled, shuffled, edges, radii)
+    assert torch.equal(again, full[perm])
+    sub = perm[:20000]
+    part = multiscale.process_gpu(dev[sub].contiguous(), dev, edges, radii)
+    assert torch.equal(part, full[sub])
+    f = full.cpu().numpy()
+    for s in range(len(edges)):
+        n, l1, l2 = f[:, 4 * s], f[:, 4 * s + 2], f[:, 4 * s + 3]
+        assert n.min() >= 1 and n.max() <= 343
+        ok = n >= 2
+        assert np.all(l1[ok] >= 1.0 / 3.0 - 1e-12) and np.all(l1[ok] <= 1.0 + 1e-12)
+        assert np.all(l2[ok] <= l1[ok] + 1e-12) and np.all(l2[ok] >= -1e-12)
+        assert np.all(l1[ok] + l2[ok] <= 1.0 + 1e-12)
+    rows = sub.cpu().numpy()
+    want = oracle.process_fast(pts[rows], pts, edges, radii)
+    assert_features_close(f[rows], want, pts)
