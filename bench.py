@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3_scene_10m")
     ap.add_argument("--points", type=int, default=None, help="points per GPU (default: the config's)")
-    ap.add_argument("--cpu-sample", type=int, default=40000,
+    ap.add_argument("--cpu-sample", type=int, default=150000,
                     help="points of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 

@@ -55,12 +55,23 @@ __global__ __launch_bounds__(256) void k_bounds(const double* __restrict__ xyz, 
             hi[a] = fmax(hi[a], __shfl_xor(hi[a], off));
         }
     }
+    // one atomic set per block: same-address atomics serialise
+    __shared__ double slo[4][3], shi[4][3];
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin((unsigned long long*)&mm[a], (unsigned long long)nm_order_encode(lo[a]));
-            atomicMax((unsigned long long*)&mm[3 + a], (unsigned long long)nm_order_encode(hi[a]));
+            slo[w][a] = lo[a];
+            shi[w][a] = hi[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const double l = fmin(fmin(slo[0][a], slo[1][a]), fmin(slo[2][a], slo[3][a]));
+        const double h = fmax(fmax(shi[0][a], shi[1][a]), fmax(shi[2][a], shi[3][a]));
+        atomicMin((unsigned long long*)&mm[a], (unsigned long long)nm_order_encode(l));
+        atomicMax((unsigned long long*)&mm[3 + a], (unsigned long long)nm_order_encode(h));
     }
 }
 
@@ -83,7 +94,7 @@ extern "C" int nm_bounds(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t st
     uint64_t* mm = (uint64_t*)d_minmax;
     k_bounds_init<<<1, 64, 0, s>>>(mm);
     int64_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;
     k_bounds<<<(int)blocks, 256, 0, s>>>(d_xyz, n, stride, mm);
     k_bounds_finish<<<1, 64, 0, s>>>(mm);
     NM_HIP(ctx, hipGetLastError());
@@ -353,73 +364,130 @@ __global__ __launch_bounds__(256) void k_cell_keys(const double* __restrict__ xy
     val[i] = (uint32_t)i;
 }
 
+// both index kernels walk the sorted keys in contiguous chunks: a 256-thread block owns
+// INDEX_CHUNK keys, each of its 4 waves a contiguous quarter, 64 keys per iteration.  counters are
+// bumped once per block (same-address atomics serialise at ~10 ns each on this chip).
+constexpr int INDEX_ITERS = 16;
+constexpr int INDEX_WAVE_KEYS = 64 * INDEX_ITERS;        // 1024 keys per wave
+constexpr int INDEX_CHUNK = 4 * INDEX_WAVE_KEYS;         // 4096 keys per block
+
 // pass A: the first key of every superblock allocates a leaf, zeroes it and publishes key -> leaf in
-// the hash table.  one atomicAdd per block on the leaf counter.
+// the hash table.
 __global__ __launch_bounds__(256) void k_index_leaves(const uint64_t* __restrict__ skey, int64_t n,
                                                       IndexDev I)
 {
-    __shared__ uint32_t wcount[4];
-    __shared__ uint32_t block_base;
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    bool head = false;
-    uint64_t sb = 0;
-    if (i < n) {
-        sb = skey[i] >> NM_LOCAL_BITS;
-        head = (i == 0) || ((skey[i - 1] >> NM_LOCAL_BITS) != sb);
+    __shared__ uint32_t wtotal[4];
+    __shared__ uint32_t wbase[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
+    // count the superblock heads of this wave's keys
+    uint32_t total = 0;
+    for (int it = 0; it < INDEX_ITERS; ++it) {
+        const int64_t i = wave_lo + it * 64 + lane;
+        bool head = false;
+        if (i < n) {
+            const uint64_t sb = skey[i] >> NM_LOCAL_BITS;
+            head = (i == 0) || ((skey[i - 1] >> NM_LOCAL_BITS) != sb);
+        }
+        total += (uint32_t)__popcll(__ballot(head));
     }
-    unsigned long long m = __ballot(head);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) wcount[w] = (uint32_t)__popcll(m);
+    if (lane == 0) wtotal[w] = total;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t t = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-        block_base = t ? atomicAdd(&I.counters[0], t) : 0u;
+        const uint32_t t = wtotal[0] + wtotal[1] + wtotal[2] + wtotal[3];
+        uint32_t base = t ? atomicAdd(&I.counters[0], t) : 0u;
+        for (int ww = 0; ww < 4; ++ww) {
+            wbase[ww] = base;
+            base += wtotal[ww];
+        }
     }
     __syncthreads();
-    if (!head) return;
-    uint32_t idx = block_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (int ww = 0; ww < w; ++ww) idx += wcount[ww];
-    if (idx >= I.leaf_capacity) {
-        I.counters[2] = 1u;   // cannot happen when the workspace was sized by the library
-        return;
-    }
-    uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
-#pragma unroll
-    for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t slot = nm_hash64(sb) & I.hash_mask;
-    for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long*)&I.hash_key[slot],
-                                            (unsigned long long)NM_HASH_EMPTY,
-                                            (unsigned long long)sb);
-        if (prev == NM_HASH_EMPTY) {
-            I.hash_val[slot] = idx;
-            break;
+    if (total == 0) return;
+    uint32_t running = wbase[w];
+    for (int it = 0; it < INDEX_ITERS; ++it) {
+        const int64_t i = wave_lo + it * 64 + lane;
+        bool head = false;
+        uint64_t sb = 0;
+        if (i < n) {
+            sb = skey[i] >> NM_LOCAL_BITS;
+            head = (i == 0) || ((skey[i - 1] >> NM_LOCAL_BITS) != sb);
         }
-        slot = (slot + 1) & I.hash_mask;
+        const unsigned long long m = __ballot(head);
+        if (head) {
+            const uint32_t idx = running + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (idx >= I.leaf_capacity) {
+                I.counters[2] = 1u;   // cannot happen when the workspace was sized by the library
+            } else {
+                uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
+#pragma unroll
+                for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
+                uint32_t slot = nm_hash64(sb) & I.hash_mask;
+                for (;;) {
+                    const unsigned long long prev =
+                        atomicCAS((unsigned long long*)&I.hash_key[slot],
+                                  (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
+                    if (prev == NM_HASH_EMPTY) {
+                        I.hash_val[slot] = idx;
+                        break;
+                    }
+                    slot = (slot + 1) & I.hash_mask;
+                }
+            }
+        }
+        running += (uint32_t)__popcll(m);
     }
 }
 
-// pass B: the first key of every distinct cell sets its bit in the leaf; M is counted on the way.
+// pass B: set the occupancy bit of every key's cell.  per 64 keys: one hash lookup per run of equal
+// superblock (broadcast to the run), a segmented OR over runs of equal row word, and one atomicOr per
+// run (runs may continue in the next 64 keys, hence atomic).  distinct cells (= M) are counted on the
+// way, one counter update per block.
 __global__ __launch_bounds__(256) void k_index_bits(const uint64_t* __restrict__ skey, int64_t n,
                                                     IndexDev I)
 {
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    bool head = false;
-    uint64_t k = 0;
-    if (i < n) {
-        k = skey[i];
-        head = (i == 0) || (skey[i - 1] != k);
-    }
-    if (head) {
-        int32_t leaf = nm_hash_find(I, k >> NM_LOCAL_BITS);
-        if (leaf >= 0) {
-            uint32_t local = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
-            atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)],
-                     1u << (local & 31u));
+    __shared__ uint32_t wcells[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
+    uint32_t cells = 0;
+    for (int it = 0; it < INDEX_ITERS; ++it) {
+        const int64_t i = wave_lo + it * 64 + lane;
+        if (wave_lo + it * 64 >= n) break;
+        const bool valid = i < n;
+        const uint64_t k = valid ? skey[i] : 0ull;
+        const uint64_t prev = (valid && i > 0) ? skey[i - 1] : ~k;
+        const bool cell_head = valid && (k != prev);
+        // run heads within this group of 64: lane 0 always starts a run
+        const bool row_head = lane == 0 || (k >> NM_SBX_BITS) != (prev >> NM_SBX_BITS) || !valid;
+        const bool sb_head = lane == 0 || (k >> NM_LOCAL_BITS) != (prev >> NM_LOCAL_BITS) || !valid;
+        cells += (uint32_t)__popcll(__ballot(cell_head));
+        const unsigned long long below = (2ull << lane) - 1ull;   // lanes <= this one
+        // superblock -> leaf: looked up by the run's first lane, fetched by everyone in the run
+        const unsigned long long sbm = __ballot(sb_head);
+        int32_t leaf = -1;
+        if (sb_head && valid) leaf = nm_hash_find(I, k >> NM_LOCAL_BITS);
+        leaf = __shfl(leaf, 63 - __clzll((long long)(sbm & below)));
+        // segmented OR of the bits of one row word
+        const unsigned long long rowm = __ballot(row_head);
+        const int seg_start = 63 - __clzll((long long)(rowm & below));
+        uint32_t bits = valid ? (1u << ((uint32_t)k & 31u)) : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t other = __shfl_up(bits, off);
+            if (lane - off >= seg_start) bits |= other;
+        }
+        // the last lane of a run holds the run's OR
+        const bool tail = valid && (lane == 63 || ((rowm >> (lane + 1)) & 1ull) || i + 1 >= n);
+        if (tail && leaf >= 0) {
+            const uint32_t local = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
+            atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)], bits);
         }
     }
-    unsigned long long m = __ballot(head);
-    if (m && (threadIdx.x & 63) == 0) atomicAdd(&I.counters[1], (uint32_t)__popcll(m));
+    if (lane == 0) wcells[w] = cells;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = wcells[0] + wcells[1] + wcells[2] + wcells[3];
+        if (t) atomicAdd(&I.counters[1], t);
+    }
 }
 
 static uint64_t lattice_superblocks(const LatticeDev& L)
@@ -467,7 +535,7 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
     I.leaf_capacity = lay.leaf_capacity;
     NM_HIP(ctx, hipMemsetAsync(I.hash_key, 0xFF, (size_t)lay.hash_capacity * 8, s));
     NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
-    int blocks = (int)((n + 255) / 256);
+    int blocks = (int)((n + INDEX_CHUNK - 1) / INDEX_CHUNK);
     k_index_leaves<<<blocks, 256, 0, s>>>(key_sorted, n, I);
     k_index_bits<<<blocks, 256, 0, s>>>(key_sorted, n, I);
     NM_HIP(ctx, hipGetLastError());
