@@ -116,7 +116,8 @@ int nm_address_to_coordinate(nm_ctx* ctx, const int64_t* d_addr, int64_t m, cons
  * neighborhoods with fewer than 2 voxels get zero eigen-features, empty ones zero centroid
  * (multiscale.py:4-5).  d_info (device int64[4], nullable) receives {M = number of occupied voxels,
  * number of neighborhoods with population < 2, passes taken by the search kernel, reserved}.
- * the query cloud may be the search cloud (same pointer, size and stride): it is then indexed once. */
+ * the query cloud may be the search cloud, or its leading n_query rows (same pointer and stride,
+ * n_query <= n_search): the cloud is then sorted and indexed once.                                  */
 size_t nm_scale_workspace_bytes(int64_t n_query, int64_t n_search, const nm_lattice* lat);
 int nm_scale_features(nm_ctx* ctx,
                       const double* d_query, int64_t n_query, int64_t query_stride,
@@ -144,6 +145,24 @@ int nm_scale_neighbors(nm_ctx* ctx,
 int nm_neighborhood_features(nm_ctx* ctx, const double* d_points, const int64_t* d_offsets,
                              const double* d_query, int64_t n_neighborhoods,
                              double* d_feat, int64_t feat_stride, void* stream);
+
+/* ---- multi-GPU tiling: halo selection -------------------------------------------------------------
+ * no reference counterpart in nimrud/minimal (it is single-process); the legacy partitioners pair a
+ * query tile with a search tile grown by the largest scale (prototypes/mso.py:892-927,
+ * utils/geometry.py:203-253).  a rank owns one spatial tile; d_boxes holds one axis-aligned box per
+ * rank (n_boxes x 6 doubles: lo xyz, hi xyz, already grown by the halo margin), `skip` is the
+ * caller's own rank.  nm_halo_count writes, per destination box, how many of the caller's points lie
+ * inside it (inclusive); nm_halo_pack writes those points as rows of 3 doubles into d_out, the rows
+ * of destination b starting at row d_offsets[b] (order within a destination is unspecified);
+ * d_cursor is int64[n_boxes] scratch.  the packed rows are what goes through RCCL's all-to-all.
+ * nm_copy_xyz copies the geometry columns of a strided cloud into (n,3) contiguous rows.            */
+int nm_halo_count(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const double* d_boxes,
+                  int32_t n_boxes, int32_t skip, int64_t* d_counts, void* stream);
+int nm_halo_pack(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const double* d_boxes,
+                 int32_t n_boxes, int32_t skip, const int64_t* d_offsets, int64_t* d_cursor,
+                 double* d_out, void* stream);
+int nm_copy_xyz(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, double* d_out,
+                void* stream);
 
 /* ---- classifier slot -------------------------------------------------------------------------------
  * nimrud/minimal/classification.py is a stub; the reference's classifier is sklearn's

@@ -66,6 +66,10 @@ SIGNATURES = {
                             c_ptr, c_ptr]),
     "nm_neighborhood_features": (ctypes.c_int,
                                  [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    "nm_halo_count": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_ptr]),
+    "nm_halo_pack": (ctypes.c_int,
+                     [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nm_copy_xyz": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "nm_forest_eval": (ctypes.c_int,
                        [c_ptr, ctypes.POINTER(NmForest), c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
 }

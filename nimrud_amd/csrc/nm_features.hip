@@ -29,7 +29,8 @@ constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anch
 
 struct ScaleArgs {
     const double* query;
-    int64_t nq;
+    int64_t nq;              // rows of the query cloud
+    int64_t n_slots;         // entries of `order` (= nq, or the search size when queries are a prefix)
     int64_t qstride;
     const uint32_t* order;   // order[slot] = query row processed in sorted slot `slot`
     LatticeDev L;
@@ -212,11 +213,14 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
 
     const int64_t batch = nm_xcd_batch(blockIdx.x, gridDim.x);
     const int64_t slot = batch * 64 + lane;
-    const bool have = slot < A.nq;
+    bool have = slot < A.n_slots;
     uint32_t qi = 0;
     double qx = 0.0, qy = 0.0, qz = 0.0;
     if (have) {
         qi = A.order[slot];
+        have = qi < A.nq;    // prefix mode: the sorted order also holds the non-query search rows
+    }
+    if (have) {
         const double* p = A.query + (int64_t)qi * A.qstride;
         qx = p[0];
         qy = p[1];
@@ -391,8 +395,9 @@ __global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
 {
     const LatticeDev& L = A.L;
     const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (slot >= A.nq) return;
+    if (slot >= A.n_slots) return;
     const uint32_t qi = A.order[slot];
+    if (qi >= A.nq) return;
     const double* p = A.query + (int64_t)qi * A.qstride;
     const double qx = p[0], qy = p[1], qz = p[2];
     const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
@@ -551,7 +556,9 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
     if (W < 0) NM_FAIL(ctx, NM_ERR_RADIUS, "radius/edge ratio %g is outside the supported range",
                        radius / lat->edge);
 
-    const bool shared = (d_query == d_search && n_query == n_search && query_stride == search_stride);
+    // the query cloud is the search cloud, or its leading rows: sort and index once
+    const bool shared = (d_query == d_search && n_query <= n_search && n_query > 0 &&
+                         query_stride == search_stride);
     ScaleLayout S;
     scale_layout(n_query > 0 ? n_query : 1, n_search, L, shared, &S);
     if (work_bytes < S.total)
@@ -588,6 +595,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         ScaleArgs A;
         A.query = d_query;
         A.nq = n_query;
+        A.n_slots = shared ? n_search : n_query;
         A.qstride = query_stride;
         A.order = order;
         A.L = L;
@@ -598,7 +606,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.feat = d_feat;
         A.fstride = feat_stride;
         A.stats = I.counters + 8;
-        const int blocks = (int)((n_query + 63) / 64);
+        const int blocks = (int)((A.n_slots + 63) / 64);
         switch (W) {
             case 3: k_scale_features<3><<<blocks, 64, 0, s>>>(A); break;
             case 5: k_scale_features<5><<<blocks, 64, 0, s>>>(A); break;

@@ -1,0 +1,219 @@
+"""
+multi-GPU execution of the multiscale pipeline: one process per GPU, one spatial tile per rank, halo
+exchange over RCCL (torch.distributed backend "nccl" on ROCm) and then the single-GPU scale loop.
+
+the reference is single-process; what it does have is the idea - its legacy partitioners pair each
+query tile with a search tile grown by the largest scale (prototypes/mso.py:892-927,
+prototypes/apc.py:399-428,595, utils/geometry.py:203-253).  here:
+
+  1. every rank holds one tile of the cloud (its rows are its query points).
+  2. all-reduce (MIN/MAX, 6 doubles): the GLOBAL per-axis extrema, so that every rank builds the same
+     lattice as a single-process run on the whole cloud (geometry.py:37: min_corner = min - e/2).
+  3. all-gather (6 doubles per rank): every tile's bounding box.
+  4. all-to-all-v: each rank sends rank j the points of its tile that lie within
+     margin = max_s(radius_s + sqrt(3)/2 * edge_s) of j's box.  a voxel centre within radius of one of
+     j's query points can only be occupied by points that close, so after the exchange every voxel j
+     can see is occupied on j exactly when it is occupied in the global cloud.  point-to-point volume:
+     each pair talks over its own xGMI link; nothing is reduced.
+  5. the scale loop on [own tile | received halo] with the global lattice; queries are the leading
+     rows of that buffer, so it is sorted and indexed once per scale.
+
+features are bit-identical to a single-GPU run over the whole cloud (integer moments of identical
+voxel sets); they stay on the owning rank, rows aligned with its tile.
+
+`backend` is the seam the CPU tests use: HipBackend (the product) drives libnimrud_hip.so; the tests
+substitute a numpy backend to exercise the collectives over gloo on machines without a GPU.
+"""
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from nimrud_amd import device as _device
+
+
+def halo_margin(edge_lengths, radii):
+    """distance beyond a tile's bounding box from which search points can still matter."""
+    return max(r + 0.5 * math.sqrt(3.0) * e * (1.0 + 1e-12) for e, r in zip(edge_lengths, radii))
+
+
+class HipBackend(object):
+    """the data-path operations of a tile, on the GPU through the C ABI."""
+
+    def __init__(self, device=None):
+        self.rt = _device.get_runtime(device)
+        self.device = self.rt.device
+
+    def bounds(self, cloud):
+        lo, hi = _device.cloud_bounds(self.rt, cloud)
+        return torch.from_numpy(np.concatenate((lo, hi))).to(self.device)
+
+    def halo_count(self, cloud, boxes, skip):
+        rt = self.rt
+        counts = torch.empty(boxes.shape[0], dtype=torch.int64, device=self.device)
+        rt.check(rt.lib.nm_halo_count(rt.ctx, _device.ptr(cloud), cloud.shape[0],
+                                      _device.row_stride(cloud), _device.ptr(boxes), boxes.shape[0],
+                                      skip, _device.ptr(counts), rt.stream()))
+        return counts
+
+    def halo_pack(self, cloud, boxes, skip, offsets, total):
+        rt = self.rt
+        out = torch.empty((max(total, 1), 3), dtype=torch.float64, device=self.device)
+        cursor = torch.empty(boxes.shape[0], dtype=torch.int64, device=self.device)
+        rt.check(rt.lib.nm_halo_pack(rt.ctx, _device.ptr(cloud), cloud.shape[0],
+                                     _device.row_stride(cloud), _device.ptr(boxes), boxes.shape[0],
+                                     skip, _device.ptr(offsets), _device.ptr(cursor),
+                                     _device.ptr(out), rt.stream()))
+        return out[:total]
+
+    def copy_xyz(self, cloud, out):
+        rt = self.rt
+        rt.check(rt.lib.nm_copy_xyz(rt.ctx, _device.ptr(cloud), cloud.shape[0],
+                                    _device.row_stride(cloud), _device.ptr(out), rt.stream()))
+
+    def features(self, search, n_query, lo, hi, edge_lengths, radii, out, info):
+        """scale loop: queries are the first n_query rows of `search`."""
+        from nimrud_amd.utils import geometry
+        rt = self.rt
+        for s, (e, r) in enumerate(zip(edge_lengths, radii)):
+            vf = geometry.VoxelFilter.from_bounds(lo, hi, e, device=self.device)
+            lat = vf.nm_lattice
+            nbytes = rt.lib.nm_scale_workspace_bytes(n_query, search.shape[0], ctypes.byref(lat))
+            work = rt.workspace(nbytes)
+            view = out[:, 4 * s:4 * s + 4]
+            rt.check(rt.lib.nm_scale_features(
+                rt.ctx, _device.ptr(search), n_query, 3, _device.ptr(search), search.shape[0], 3,
+                ctypes.byref(lat), float(r), _device.ptr(view), int(view.stride(0)),
+                _device.ptr(info[s]), _device.ptr(work), work.numel(), rt.stream()))
+
+
+class TilePlan(object):
+    """one rank's share of a multi-GPU job: `cloud` is this rank's tile, (N, >=3) fp64 on this rank's
+    device (a numpy array is uploaded).  edge_lengths / radii as in process_single_core."""
+
+    def __init__(self, cloud, edge_lengths, radii, group=None, backend=None):
+        assert len(edge_lengths) == len(radii), \
+            "edge_lengths and radii should be equal-length sequences."
+        self.backend = backend if backend is not None else HipBackend(
+            cloud.device if isinstance(cloud, torch.Tensor) and cloud.is_cuda else None)
+        if isinstance(self.backend, HipBackend):
+            cloud = _device.as_cloud(cloud, self.backend.device)[1]
+        self.cloud = cloud
+        self.edge_lengths = list(edge_lengths)
+        self.radii = list(radii)
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.margin = halo_margin(self.edge_lengths, self.radii) if self.edge_lengths else 0.0
+        # RCCL moves device buffers directly.  a gloo group (CPU rehearsals on a one-GPU box) cannot,
+        # so device tensors are staged through host memory for the collectives only.
+        self.stage_on_host = bool(dist.is_initialized() and dist.get_backend(group) == "gloo"
+                                  and isinstance(cloud, torch.Tensor) and cloud.is_cuda)
+        self._info = None
+        self._search_points = cloud.shape[0]
+        self.halo_sent = 0
+        self.halo_received = 0
+
+    def last_info(self):
+        from nimrud_amd.minimal.multiscale import ScaleInfo
+        host = self._info.cpu().numpy()
+        return [ScaleInfo(row) for row in host[:len(self.edge_lengths)]]
+
+    def search_points(self):
+        return self._search_points
+
+
+def exchange_halo(plan):
+    """steps 2-4: returns (global lo, global hi, received halo rows (H,3))."""
+    be, cloud, group = plan.backend, plan.cloud, plan.group
+    dev = cloud.device
+    local = be.bounds(cloud)                               # (6,) lo xyz, hi xyz on the device
+    if plan.world == 1:
+        mm = local.cpu().numpy()
+        return mm[:3], mm[3:], torch.empty((0, 3), dtype=torch.float64, device=dev)
+    cdev = torch.device("cpu") if plan.stage_on_host else dev    # where the collectives run
+    local_c = local.to(cdev)
+    glo = local_c[:3].clone()
+    ghi = local_c[3:].clone()
+    dist.all_reduce(glo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(ghi, op=dist.ReduceOp.MAX, group=group)
+    box_list = [torch.empty(6, dtype=torch.float64, device=cdev) for _ in range(plan.world)]
+    dist.all_gather(box_list, local_c.contiguous(), group=group)
+    boxes = torch.stack(box_list).to(dev)
+    boxes[:, :3] -= plan.margin
+    boxes[:, 3:] += plan.margin
+    send_counts = be.halo_count(cloud, boxes, plan.rank).to(cdev)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    send_list = [int(v) for v in send_counts.cpu()]
+    recv_list = [int(v) for v in recv_counts.cpu()]
+    offsets = torch.zeros(plan.world, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(torch.tensor(send_list[:-1], dtype=torch.int64), 0)
+    packed = be.halo_pack(cloud, boxes, plan.rank, offsets.to(dev), sum(send_list)).to(cdev)
+    recv = torch.empty((sum(recv_list), 3), dtype=torch.float64, device=cdev)
+    dist.all_to_all_single(recv.reshape(-1), packed.reshape(-1),
+                           [3 * c for c in recv_list], [3 * c for c in send_list], group=group)
+    recv = recv.to(dev)
+    plan.halo_sent, plan.halo_received = sum(send_list), sum(recv_list)
+    return glo.cpu().numpy(), ghi.cpu().numpy(), recv
+
+
+def process_tile(plan, out=None):
+    """features of this rank's tile, (N, 4*S) fp64 on this rank's device, rows aligned with the
+    tile.  collective: every rank of the group must call it."""
+    be, cloud = plan.backend, plan.cloud
+    n = cloud.shape[0]
+    n_scales = len(plan.edge_lengths)
+    lo, hi, halo = exchange_halo(plan)
+    search = torch.empty((n + halo.shape[0], 3), dtype=torch.float64, device=cloud.device)
+    be.copy_xyz(cloud, search[:n])
+    if halo.shape[0]:
+        search[n:] = halo
+    plan._search_points = search.shape[0]
+    if out is None:
+        out = torch.empty((n, 4 * n_scales), dtype=torch.float64, device=cloud.device)
+    info = torch.zeros((max(n_scales, 1), 4), dtype=torch.int64, device=cloud.device)
+    be.features(search, n, lo, hi, plan.edge_lengths, plan.radii, out, info)
+    plan._info = info
+    return out
+
+
+def process_multi_gpu(tile_cloud, edge_lengths, radii, group=None):
+    """convenience wrapper: this rank's tile in (numpy or torch), this rank's features out (same kind).
+    torch.distributed must be initialised (backend "nccl") with one rank per GPU."""
+    as_torch = isinstance(tile_cloud, torch.Tensor)
+    plan = TilePlan(tile_cloud, edge_lengths, radii, group=group)
+    out = process_tile(plan)
+    return out if as_torch else out.cpu().numpy()
+
+
+def partition_tiles(points, world):
+    """split a host cloud into `world` spatially compact tiles of (nearly) equal point count by
+    recursive median bisection along the longest axis.  the tiles' bounding boxes are disjoint, which
+    keeps the box-based halo small.  returns a list of sorted index arrays."""
+    xyz = np.asarray(points)[:, :3]
+
+    def split(idx, parts):
+        if parts == 1:
+            return [np.sort(idx)]
+        left_parts = parts // 2
+        sub = xyz[idx]
+        axis = int(np.argmax(sub.max(0) - sub.min(0)))
+        k = int(round(len(idx) * left_parts / parts))
+        order = np.argsort(sub[:, axis], kind="stable")
+        return split(idx[order[:k]], left_parts) + split(idx[order[k:]], parts - left_parts)
+
+    return split(np.arange(len(xyz)), world)
+
+
+def partition_by_morton(points, world, edge_length):
+    """split a host cloud into `world` Morton-contiguous runs of (nearly) equal point count (how a
+    Morton-ordered archive is cut into files).  correct with process_tile, but Morton runs can be
+    L-shaped, so their bounding boxes - and with them the box-based halos - can be much larger than
+    those of partition_tiles.  returns a list of index arrays."""
+    from nimrud_amd import synth
+    order = synth.morton_sort(np.asarray(points)[:, :3], edge_length)
+    return [np.sort(chunk) for chunk in np.array_split(order, world)]

@@ -47,7 +47,9 @@ class Lattice(object):
     """bounding lattice of a cloud: restates VoxelFilter.__init__/_calculate_shift/_calculate_masks
     (geometry.py:23-79)."""
 
-    def __init__(self, points, edge_length):
+    def __init__(self, points, edge_length, bounds=None):
+        """`bounds` = (per-axis min, per-axis max) overrides the extrema of `points`: the multi-rank
+        tests build the lattice of the WHOLE cloud while holding only a tile of it."""
         points = np.asarray(points)
         if points.ndim != 2:                                   # geometry.py:30
             raise ValueError("wrong point cloud array shape")
@@ -56,8 +58,10 @@ class Lattice(object):
         if points.shape[0] < 2:                                # geometry.py:34
             raise ValueError("need at least 2 points to define a voxel grid")
         self.edge_length = edge_length
-        self.minimum_corner = points.min(0) - edge_length / 2  # geometry.py:37
-        self.maximum_corner = points.max(0) + edge_length / 2  # geometry.py:38
+        lo, hi = (points.min(0), points.max(0)) if bounds is None else \
+            (np.asarray(bounds[0], dtype=np.float64), np.asarray(bounds[1], dtype=np.float64))
+        self.minimum_corner = lo - edge_length / 2             # geometry.py:37
+        self.maximum_corner = hi + edge_length / 2             # geometry.py:38
         span = self.maximum_corner - self.minimum_corner       # geometry.py:55
         widths = np.ceil(np.log2(span / edge_length))          # geometry.py:56
         if widths.sum() > MAX_ADDRESS_LENGTH:                  # geometry.py:59
@@ -225,13 +229,13 @@ def process(query_cloud, search_cloud, edge_lengths, radii, strict=False):
          for e, r in zip(edge_lengths, radii)], axis=1)
 
 
-def one_scale_fast(query_cloud, search_cloud, edge_length, radius, workers=1):
+def one_scale_fast(query_cloud, search_cloud, edge_length, radius, workers=1, bounds=None):
     """same numbers as `one_scale` but vectorised (bulk query_ball_point, segmented sums, stacked
     eigvalsh) so that 1e5-1e6-point parity cases finish in seconds.  Covariance is formed from
     mean-centred neighbor coordinates exactly like np.cov; summation order differs (<=1e-12)."""
     query_xyz = np.ascontiguousarray(np.asarray(query_cloud, dtype=np.float64)[:, :3])
     search_xyz = np.asarray(search_cloud, dtype=np.float64)[:, :3]
-    lattice = Lattice(search_xyz, edge_length)
+    lattice = Lattice(search_xyz, edge_length, bounds=bounds)
     voxels = lattice.unique_voxels(search_xyz)
     tree = cKDTree(voxels, leafsize=LEAFSIZE)
     out = np.zeros((len(query_xyz), 4))
@@ -266,10 +270,10 @@ def one_scale_fast(query_cloud, search_cloud, edge_length, radius, workers=1):
     return out
 
 
-def process_fast(query_cloud, search_cloud, edge_lengths, radii, workers=1):
+def process_fast(query_cloud, search_cloud, edge_lengths, radii, workers=1, bounds=None):
     assert len(edge_lengths) == len(radii)
     return np.concatenate(
-        [one_scale_fast(query_cloud, search_cloud, e, r, workers=workers)
+        [one_scale_fast(query_cloud, search_cloud, e, r, workers=workers, bounds=bounds)
          for e, r in zip(edge_lengths, radii)], axis=1)
 
 

@@ -164,7 +164,7 @@ def test_oracle_radius_ratios(ratio):
 def test_oracle_scene_three_scales():
     pts, _ = synth.scene_cloud(60000, extent=15.0, n_poles=12, n_spheres=3, seed=21)
     edges, radii = [0.10, 0.20, 0.40], [0.30, 0.60, 1.20]
-    got, info = multiscale.process_gpu(torch.from_numpy(pts).cuda(), None or torch.from_numpy(pts).cuda(),
+    got, info = multiscale.process_gpu(torch.from_numpy(pts).cuda(), torch.from_numpy(pts).cuda(),
                                        edges, radii, return_info=True)
     want = oracle.process_fast(pts, pts, edges, radii)
     assert_features_close(got.cpu().numpy(), want, pts)
@@ -277,3 +277,101 @@ def test_config2_full_size_properties():
     rows = sub.cpu().numpy()
     want = oracle.process_fast(pts[rows], pts, edges, radii)
     assert_features_close(f[rows], want, pts)
+
+
+# ---- multi-GPU path pieces on one GPU ---------------------------------------------------------------
+
+def test_halo_kernels_against_numpy():
+    from nimrud_amd import parallel
+    pts, _ = synth.scene_cloud(50000, extent=20.0, n_poles=10, n_spheres=4, seed=91)
+    wide = np.concatenate((pts, np.zeros((len(pts), 2))), axis=1)          # strided rows
+    cloud = torch.from_numpy(wide).cuda()
+    be = parallel.HipBackend()
+    boxes = np.array([[0, 0, -1, 8, 8, 7], [6, 6, -1, 14, 21, 7], [-5, -5, -5, 30, 30, 30],
+                      [100, 100, 100, 101, 101, 101]], dtype=np.float64)
+    dboxes = torch.from_numpy(boxes).cuda()
+    skip = 2
+    counts = be.halo_count(cloud, dboxes, skip).cpu().numpy()
+    masks = [np.all((pts >= b[:3]) & (pts <= b[3:]), axis=1) for b in boxes]
+    want = [int(m.sum()) if j != skip else 0 for j, m in enumerate(masks)]
+    assert list(counts) == want and want[0] > 0 and want[1] > 0 and want[3] == 0
+    offsets = torch.from_numpy(np.concatenate(([0], np.cumsum(want)[:-1]))).cuda()
+    packed = be.halo_pack(cloud, dboxes, skip, offsets, int(sum(want))).cpu().numpy()
+    off = 0
+    for j, m in enumerate(masks):
+        if j == skip:
+            continue
+        seg = packed[off:off + want[j]]
+        off += want[j]
+        # order within a destination is unspecified: compare as sorted row sets
+        a = seg[np.lexsort(seg.T[::-1])]
+        b = pts[m][np.lexsort(pts[m].T[::-1])]
+        assert np.array_equal(a, b)
+    out = torch.empty((len(pts), 3), dtype=torch.float64, device="cuda")
+    be.copy_xyz(cloud, out)
+    assert np.array_equal(out.cpu().numpy(), pts)
+
+
+def test_prefix_query_mode_matches_separate_clouds():
+    # queries = leading rows of the search buffer (what a tile + halo looks like)
+    pts, _ = synth.scene_cloud(40000, extent=12.0, n_poles=8, n_spheres=3, seed=93)
+    search = torch.from_numpy(pts).cuda()
+    n_query = 25000
+    from nimrud_amd import parallel
+    be = parallel.HipBackend()
+    out = torch.empty((n_query, 8), dtype=torch.float64, device="cuda")
+    info = torch.zeros((2, 4), dtype=torch.int64, device="cuda")
+    lo, hi = pts.min(0), pts.max(0)
+    be.features(search, n_query, lo, hi, [0.1, 0.2], [0.3, 0.6], out, info)
+    want = multiscale.process_gpu(search[:n_query].clone(), search, [0.1, 0.2], [0.3, 0.6])
+    assert torch.equal(out, want)
+    ref = oracle.process_fast(pts[:n_query], pts, [0.1, 0.2], [0.3, 0.6])
+    assert_features_close(out.cpu().numpy(), ref, pts)
+
+
+def test_single_rank_tile_plan_on_gpu():
+    from nimrud_amd import parallel
+    pts, _ = synth.scene_cloud(30000, extent=10.0, n_poles=6, n_spheres=2, seed=95)
+    plan = parallel.TilePlan(torch.from_numpy(pts).cuda(), [0.1, 0.2], [0.3, 0.6])
+    out = parallel.process_tile(plan)
+    want = multiscale.process_gpu(torch.from_numpy(pts).cuda(), torch.from_numpy(pts).cuda(),
+                                  [0.1, 0.2], [0.3, 0.6])
+    assert torch.equal(out, want)
+
+
+def _two_rank_worker(rank, world, port, points, parts, results):
+    import os
+    import torch.distributed as dist
+    from nimrud_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tile = torch.from_numpy(np.ascontiguousarray(points[parts[rank]])).cuda()
+        plan = parallel.TilePlan(tile, [0.1, 0.2, 0.4], [0.3, 0.6, 1.2])
+        out = parallel.process_tile(plan)
+        results[rank] = (out.cpu().numpy(), plan.halo_received)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_hip_backend():
+    # both ranks run the HIP data path on cuda:0; the collectives go over gloo (staged through host
+    # memory) because RCCL needs one GPU per rank.  result must equal the single-GPU run.
+    import socket
+    import torch.multiprocessing as mp
+    from nimrud_amd import parallel
+    points, _ = synth.scene_cloud(60000, extent=30.0, n_poles=20, n_spheres=6, seed=97)
+    parts = parallel.partition_tiles(points, 2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_two_rank_worker, args=(2, port, points, parts, results), nprocs=2, join=True)
+    dev = torch.from_numpy(points).cuda()
+    whole = multiscale.process_gpu(dev, dev, [0.1, 0.2, 0.4], [0.3, 0.6, 1.2]).cpu().numpy()
+    for rank in range(2):
+        out, received = results[rank]
+        assert np.array_equal(out, whole[parts[rank]])       # bit-identical
+        assert 0 < received < len(points) - len(parts[rank])
