@@ -81,10 +81,17 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                          % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  NIMRUD_BENCH_BACKEND=gloo lets several ranks share a GPU to rehearse the
+    # multi-rank code path on a one-GPU box (collectives staged through host memory; not a benchmark).
+    backend = os.environ.get("NIMRUD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- synthetic input: one tile per rank, tiles side by side along x ---------------------------
     cfg = synth.CONFIGS[args.workload]
@@ -110,6 +117,7 @@ def main():
             return multiscale.process_gpu(cloud, cloud, edges, radii, out=out)
 
     def fence():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -135,14 +143,15 @@ def main():
     n_local_search = cloud.shape[0] if world == 1 else plan.search_points()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([cloud.shape[0]], dtype=torch.int64, device=dev)
+        tot = torch.tensor([cloud.shape[0], plan.halo_received], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
-        total_points = int(tot.item())
+        total_points, total_halo = int(tot[0].item()), int(tot[1].item())
     else:
-        total_points = cloud.shape[0]
+        total_points, total_halo = cloud.shape[0], 0
 
     if rank == 0:
         point_scales = total_points * n_scales * args.steps
@@ -174,6 +183,9 @@ def main():
                 "scales": n_scales,
                 "parallelism": "tiles%d" % world,
                 "search_points_incl_halo": int(n_local_search),
+                "halo_points_exchanged_per_step": int(total_halo),
+                "collectives": "none" if world == 1 else
+                               "all-reduce(6 f64) + all-gather(6 f64) + 2x all-to-all-v per step",
             },
             "roofline": {
                 "bound": "hbm",
