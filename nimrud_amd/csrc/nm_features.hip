@@ -70,10 +70,22 @@ __device__ __forceinline__ void nm_eig3(double a00, double a01, double a02, doub
     const double det = c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) +
                        c02 * (c01 * c12 - c11 * c02);
     const double r = fmin(fmax(det * 0.5, -1.0), 1.0);
-    const double phi = acos(r) * (1.0 / 3.0);
-    // r >= 0: the largest eigenvalue is the separated one; r < 0: the smallest
+    // with x = (lambda - q)/p the characteristic cubic is x^3 - 3x - 2r = 0, roots 2cos(phi + 2k*pi/3).
+    // r >= 0: the largest root (in [sqrt3, 2]) is the separated one; r < 0: the smallest (mirror
+    // image).  Newton from x = 2 descends monotonically onto that root; f' >= 6 there, so it is
+    // quadratic and well conditioned.  (this replaces acos/cos: the fp64 library versions cost ~100
+    // registers, i.e. two waves of occupancy.)  the approximate reciprocal only perturbs the step.
     const bool top = r >= 0.0;
-    const double lam = top ? q + 2.0 * p * cos(phi) : q + 2.0 * p * cos(phi + 2.0943951023931954923);
+    const double ra = fabs(r);
+    double x = 2.0;
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        const double x2 = x * x;
+        const double f = x * (x2 - 3.0) - 2.0 * ra;
+        const double fp = 3.0 * x2 - 3.0;
+        x = x - f * __builtin_amdgcn_rcp(fp);
+    }
+    const double lam = top ? q + p * x : q - p * x;
 
     // eigenvector of lam: the cross product of two rows of (A - lam*I) with the largest norm
     const double m00 = a00 - lam, m11 = a11 - lam, m22 = a22 - lam;
@@ -87,12 +99,14 @@ __device__ __forceinline__ void nm_eig3(double a00, double a01, double a02, doub
     if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
     if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
     if (!(nn > 0.0)) {
-        // (A - lam*I) has rank <= 1: lam is (numerically) a double root after all; fall back to the
-        // cubic's values, which are then exact enough (all three within rounding of q +- p)
-        const double la = q + 2.0 * p * cos(phi), lc = q + 2.0 * p * cos(phi + 2.0943951023931954923);
-        l0 = la;
-        l2 = lc;
-        l1 = 3.0 * q - la - lc;
+        // (A - lam*I) has rank <= 1: the other two eigenvalues coincide; they share what is left of
+        // the trace
+        const double rest = 0.5 * (3.0 * q - lam);
+        if (top) {
+            l0 = lam; l1 = rest; l2 = rest;
+        } else {
+            l0 = rest; l1 = rest; l2 = lam;
+        }
         return;
     }
     const double vn = 1.0 / sqrt(nn);
@@ -137,9 +151,10 @@ __device__ __forceinline__ void nm_features_from_moments(
     out[3] = 0.0;
     if (n < 1.0) return;
     // centroid (features.py:21-29): mean of the neighbor centres = home centre + e*(S1/n + dmin)
-    double mx = ux - (sx / n + dmin) * edge;
-    double my = uy - (sy / n + dmin) * edge;
-    double mz = uz - (sz / n + dmin) * edge;
+    const double inv_n = 1.0 / n;
+    double mx = ux - (sx * inv_n + dmin) * edge;
+    double my = uy - (sy * inv_n + dmin) * edge;
+    double mz = uz - (sz * inv_n + dmin) * edge;
     out[1] = sqrt(mx * mx + my * my + mz * mz);
     if (n < 2.0) return;   // covariance undefined: zeros (multiscale.py:4-5)
     // n*(n-1)/e^2 times the ddof=1 covariance (features.py:43), exact in integers:
@@ -149,8 +164,9 @@ __device__ __forceinline__ void nm_features_from_moments(
     double l0, l1, l2;
     nm_eig3(a00, a01, a02, a11, a12, a22, l0, l1, l2);
     double tr = a00 + a11 + a22;      // = l0 + l1 + l2 (features.py:55)
-    out[2] = l0 / tr;
-    out[3] = l1 / tr;
+    const double inv_tr = 1.0 / tr;
+    out[2] = l0 * inv_tr;
+    out[3] = l1 * inv_tr;
 }
 
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
@@ -185,10 +201,66 @@ __device__ __forceinline__ int64_t nm_xcd_batch(int64_t b, int64_t nb)
     return base + (b >> 3);
 }
 
+// ---- static geometry of the candidate window ---------------------------------------------------------
+// whatever the position of a query inside its home cell, candidate (dx,dy,dz) (cell offsets) lies at a
+// distance between sqrt(sum max(|d|-1/2,0)^2) and sqrt(sum (|d|+1/2)^2) cells.  so for the row
+// (dy,dz) of the window the x-candidates split, symmetrically about the centre, into
+//   |dx| <= a : always inside  (no test)      a < |dx| <= b : must be tested      |dx| > b : never
+// at r = 3e only 194 of the 343 candidates need the fp64 test.  eta pads the cell by 1e-4 cells for
+// the rounding of the home-cell assignment and of the voxel centres (the host only enables pruning
+// when 16 ulp of the largest coordinate is below that, see nm_scale_features).
+struct RowBound {
+    int8_t a, b;
+};
+
+constexpr double nm_sq(double v) { return v * v; }
+constexpr double nm_pos(double v) { return v > 0.0 ? v : 0.0; }
+
+constexpr RowBound nm_row_bound(int W, double rho2, int j, int k)
+{
+    const int c = (W - 1) / 2;
+    const double eta = 1e-4;
+    const double ady = (double)(j > c ? j - c : c - j), adz = (double)(k > c ? k - c : c - k);
+    int a = -1, b = -1;
+    for (int ax = 0; ax <= c; ++ax) {
+        const double far2 = nm_sq(ax + 0.5 + eta) + nm_sq(ady + 0.5 + eta) + nm_sq(adz + 0.5 + eta);
+        const double near2 = nm_sq(nm_pos(ax - 0.5 - eta)) + nm_sq(nm_pos(ady - 0.5 - eta)) +
+                             nm_sq(nm_pos(adz - 0.5 - eta));
+        if (far2 <= rho2 * (1.0 - 1e-9) && a == ax - 1) a = ax;
+        if (near2 <= rho2 * (1.0 + 1e-9)) b = ax;
+    }
+    return RowBound{(int8_t)a, (int8_t)b};
+}
+
+constexpr int NM_MAX_W = 9;
+struct RowBoundTable {
+    RowBound rb[NM_MAX_W * NM_MAX_W];   // [j * W + k]
+};
+
 template <int W>
-__global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
+constexpr RowBoundTable nm_make_bounds(double rho2, bool prune)
+{
+    RowBoundTable t{};
+    for (int j = 0; j < W; ++j)
+        for (int k = 0; k < W; ++k)
+            t.rb[j * W + k] = prune ? nm_row_bound(W, rho2, j, k)
+                                    : RowBound{(int8_t)-1, (int8_t)((W - 1) / 2)};
+    return t;
+}
+
+// the benchmark ratio r = 3e gets its table at compile time, so the unrolled loops contain only the
+// tests that can matter
+constexpr RowBoundTable NM_BOUNDS_RHO3 = nm_make_bounds<7>(9.0, true);
+
+// packed LUT fields: bits [0,8) count, [8,20) sum of bit index, [20,32) sum of index^2
+template <int W, bool RHO3>
+__global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTable RT)
 {
     static_assert(W >= 3 && W <= 9 && (W & 1), "LUT kernel covers W = 3,5,7,9");
+    static_assert(!RHO3 || W == 7, "the compile-time table is for W = 7");
+    constexpr int C = (W - 1) / 2;
+    constexpr int ROWS_PER_REG = 32 / W;                          // packed mask fields per VGPR
+    constexpr int MASK_REGS = (W * W + ROWS_PER_REG - 1) / ROWS_PER_REG;
     __shared__ uint64_t rows[ROWS_CAP];
     __shared__ int32_t sbt[SBT_CAP];
     __shared__ uint32_t lut[1 << W];
@@ -198,7 +270,6 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
     const int32_t dmin = A.dmin;
     const int32_t dmax = dmin + W - 1;
 
-    // packed per-mask sums: bits [0,8) count, [8,20) sum of bit index, [20,32) sum of index^2
     for (int m = lane; m < (1 << W); m += 64) {
         uint32_t n = 0, s1 = 0, s2 = 0;
 #pragma unroll
@@ -241,16 +312,54 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
         o[3] = 0.0;
     }
 
-    // squared coordinate differences to the W candidate centres per axis (bit-identical centres)
-    double dx2[W], dy2[W], dz2[W];
+    // ---- phase A (once per wave): the inside/outside bit of every candidate that needs a test, as
+    //      W-bit row masks packed ROWS_PER_REG to a register.  independent of the occupancy.
+    uint32_t inside[MASK_REGS];
+    {
+        // squared coordinate differences to the W candidate centres per axis (bit-identical centres)
+        double dx2[W], dy2[W], dz2[W];
 #pragma unroll
-    for (int i = 0; i < W; ++i) {
-        double d = qx - nm_centre(hx + dmin + i, L.min_x, L.edge, L.half_edge);
-        dx2[i] = d * d;
-        d = qy - nm_centre(hy + dmin + i, L.min_y, L.edge, L.half_edge);
-        dy2[i] = d * d;
-        d = qz - nm_centre(hz + dmin + i, L.min_z, L.edge, L.half_edge);
-        dz2[i] = d * d;
+        for (int i = 0; i < W; ++i) {
+            double d = qx - nm_centre(hx + dmin + i, L.min_x, L.edge, L.half_edge);
+            dx2[i] = d * d;
+            d = qy - nm_centre(hy + dmin + i, L.min_y, L.edge, L.half_edge);
+            dy2[i] = d * d;
+            d = qz - nm_centre(hz + dmin + i, L.min_z, L.edge, L.half_edge);
+            dz2[i] = d * d;
+        }
+#pragma unroll
+        for (int r = 0; r < MASK_REGS; ++r) inside[r] = 0u;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            double pxy[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) pxy[i] = dx2[i] + dy2[j];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const RowBound rb = RHO3 ? NM_BOUNDS_RHO3.rb[j * W + k] : RT.rb[j * W + k];
+                // "outside" bits, candidate i in bit i; candidates that are never inside start as 1
+                uint32_t outside = 0u;
+#pragma unroll
+                for (int i = W - 1; i >= 0; --i) {
+                    const int ad = i > C ? i - C : C - i;
+                    if (ad > rb.b) {
+                        outside = (outside << 1) | 1u;
+                    } else if (ad <= rb.a) {
+                        outside = outside << 1;
+                    } else {
+                        const double s = pxy[i] + dz2[k];
+                        const double t = A.r2 - s;     // sign bit set  <=>  s > r^2  (exact)
+                        outside = __builtin_amdgcn_alignbit(outside, (uint32_t)__double2hiint(t), 31);
+                    }
+                }
+                constexpr uint32_t FULL = (1u << W) - 1u;
+                const int row = j * W + k;
+                inside[row / ROWS_PER_REG] |= ((~outside) & FULL) << ((row % ROWS_PER_REG) * W);
+            }
+            // keep the rows of different j apart: without this the scheduler interleaves all W*W
+            // chains and the live set (W*W partial sums) costs two waves of occupancy
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     lds_fence();
 
@@ -291,6 +400,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
         const int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - sby0 + 1;
         const int32_t nsz = ((oz + ez - 1) >> NM_SBZ_BITS) - sbz0 + 1;
         const int32_t nsb = 3 * nsy * nsz;
+#pragma nounroll
         for (int32_t t = lane; t < nsb; t += 64) {
             int32_t ix = t % 3, iy = (t / 3) % nsy, iz = t / (3 * nsy);
             int32_t sx = sbx0 + ix, sy = sby0 + iy, sz = sbz0 + iz;
@@ -303,6 +413,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
         // ---- stage: 64-bit x-rows of the box, funnel-shifted out of the 32-bit leaf words
         const int32_t nrows = ey * ez;
         const uint32_t sh = (uint32_t)(ox & 31);
+#pragma nounroll
         for (int32_t rr = lane; rr < nrows; rr += 64) {
             int32_t y = oy + rr % ey, z = oz + rr / ey;
             int32_t t0 = (((z >> NM_SBZ_BITS) - sbz0) * nsy + ((y >> NM_SBY_BITS) - sby0)) * 3;
@@ -317,36 +428,40 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
         }
         lds_fence();
 
-        // ---- walk the W*W rows of every selected lane
+        // ---- phase B: walk the W*W rows of every selected lane.  branch-free: W row reads, then W
+        //      table reads, per j; rows nobody occupies add the table's zero entry.
         if (sel) {
             const int32_t rx = hx + dmin - ox;
             const int32_t rbase = (hz + dmin - oz) * ey + (hy + dmin - oy);
             uint32_t aj[W], bk[W], cj[W];
 #pragma unroll
             for (int i = 0; i < W; ++i) aj[i] = bk[i] = cj[i] = 0u;
+            // the packed masks are loop-invariant; without this the compiler unpacks all W*W fields
+            // ahead of the pass loop and keeps them in W*W registers
+#pragma unroll
+            for (int r = 0; r < MASK_REGS; ++r) asm volatile("" : "+v"(inside[r]));
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                double pxy[W];
-#pragma unroll
-                for (int i = 0; i < W; ++i) pxy[i] = dx2[i] + dy2[j];
+                uint32_t valid[W];
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     const uint64_t row = rows[rbase + k * ey + j];
-                    const uint32_t occ = (uint32_t)(row >> rx) & ((1u << W) - 1u);
-                    if (__ballot(occ != 0u) == 0ull) continue;   // wave-uniform: nothing occupied
-                    uint32_t outside = 0u;
+                    const int r = j * W + k;
+                    const uint32_t in =
+                        (inside[r / ROWS_PER_REG] >> ((r % ROWS_PER_REG) * W)) & ((1u << W) - 1u);
+                    valid[k] = (uint32_t)(row >> rx) & in;
+                }
 #pragma unroll
-                    for (int i = W - 1; i >= 0; --i) {
-                        double s = pxy[i] + dz2[k];
-                        double t = A.r2 - s;     // sign bit set  <=>  s > r^2  (exact)
-                        outside = __builtin_amdgcn_alignbit(
-                            outside, (uint32_t)__double2hiint(t), 31);
-                    }
-                    const uint32_t t = lut[occ & ~outside];
+                for (int k = 0; k < W; ++k) {
+                    const uint32_t t = lut[valid[k]];
                     aj[j] += t;
                     bk[k] += t;
-                    cj[j] += (t & 0xFFu) * (uint32_t)k;
+                    if (W <= 7)
+                        cj[j] += t * (uint32_t)k;          // low 8 bits = sum k*n (< 256 for W <= 7)
+                    else
+                        cj[j] += (t & 0xFFu) * (uint32_t)k;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             uint32_t n = 0, sx = 0, sxx = 0, sy = 0, syy = 0, sxy = 0, sz = 0, szz = 0, sxz = 0,
                      syz = 0;
@@ -354,6 +469,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
             for (int i = 0; i < W; ++i) {
                 uint32_t na = aj[i] & 0xFFu, xa = (aj[i] >> 8) & 0xFFFu, xxa = aj[i] >> 20;
                 uint32_t nb = bk[i] & 0xFFu, xb = (bk[i] >> 8) & 0xFFFu;
+                uint32_t cji = W <= 7 ? (cj[i] & 0xFFu) : cj[i];
                 n += na;
                 sx += xa;
                 sxx += xxa;
@@ -363,7 +479,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
                 sz += nb * i;
                 szz += nb * (i * i);
                 sxz += xb * i;
-                syz += cj[i] * i;
+                syz += cji * i;
             }
             double out[4];
             const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
@@ -381,8 +497,6 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A)
             if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
                 atomicAdd(&A.stats[0], (uint32_t)__popcll(degenerate));
             done = true;
-        } else {
-            // keep the ballot above convergent for lanes that sit this pass out
         }
         lds_fence();
     }
@@ -607,11 +721,27 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.fstride = feat_stride;
         A.stats = I.counters + 8;
         const int blocks = (int)((A.n_slots + 63) / 64);
+        // static pruning of the candidate window is sound only while the rounding of cells and
+        // centres stays far below the 1e-4-cell padding of the bounds: 16 ulp of the largest
+        // coordinate the lattice can produce must be smaller than that.
+        double maxabs = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double lo = lat->min_corner[a];
+            const double hi = lo + ldexp(lat->edge, lat->widths[a]);
+            maxabs = fmax(maxabs, fmax(fabs(lo), fabs(hi)));
+        }
+        const bool prune = 16.0 * maxabs * 2.220446049250313e-16 < 1e-4 * lat->edge;
+        const double rho = radius / lat->edge;
+        const double rho2 = rho * rho;
+        const bool rho3 = prune && W == 7 && fabs(rho - 3.0) < 1e-9;
         switch (W) {
-            case 3: k_scale_features<3><<<blocks, 64, 0, s>>>(A); break;
-            case 5: k_scale_features<5><<<blocks, 64, 0, s>>>(A); break;
-            case 7: k_scale_features<7><<<blocks, 64, 0, s>>>(A); break;
-            case 9: k_scale_features<9><<<blocks, 64, 0, s>>>(A); break;
+            case 3: k_scale_features<3, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, prune)); break;
+            case 5: k_scale_features<5, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, prune)); break;
+            case 7:
+                if (rho3) k_scale_features<7, true><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3);
+                else k_scale_features<7, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, prune));
+                break;
+            case 9: k_scale_features<9, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, prune)); break;
             default: k_scale_features_generic<<<blocks, 64, 0, s>>>(A); break;
         }
     }
