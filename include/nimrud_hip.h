@@ -126,6 +126,22 @@ int nm_scale_features(nm_ctx* ctx,
                       double* d_feat, int64_t feat_stride, int64_t* d_info,
                       void* d_work, size_t work_bytes, void* stream);
 
+/* ---- the whole scale ladder ---------------------------------------------------------------------------
+ * process_single_core (nimrud/minimal/multiscale.py:27-67) in one call: scale i uses lats[i] and
+ * radii[i] and writes columns 4i..4i+3 of the (n_query, feat_stride) matrix d_feat, scales in caller
+ * order (multiscale.py:37,56).  numerically identical to calling nm_scale_features per scale, but the
+ * cloud is sorted only once (by its cell keys at the finest lattice of the ladder; the coordinates
+ * are kept in that order) and every scale's occupancy index is built from that spatially coherent
+ * stream without a sort.  d_info (nullable) receives 4 int64 per scale as in nm_scale_features.      */
+size_t nm_multiscale_workspace_bytes(int64_t n_query, int64_t n_search, const nm_lattice* lats,
+                                     int32_t n_scales);
+int nm_multiscale_features(nm_ctx* ctx,
+                           const double* d_query, int64_t n_query, int64_t query_stride,
+                           const double* d_search, int64_t n_search, int64_t search_stride,
+                           const nm_lattice* lats, const double* radii, int32_t n_scales,
+                           double* d_feat, int64_t feat_stride, int64_t* d_info,
+                           void* d_work, size_t work_bytes, void* stream);
+
 /* ---- neighbor lists (parity / inspection mode) -----------------------------------------------------
  * the neighbor_idx lists of multiscale.py:103 as CSR.  two calls: with d_nbr_index == NULL the
  * per-query counts are written to d_nbr_count (int32[n_query]); the caller turns them into offsets

@@ -61,6 +61,11 @@ SIGNATURES = {
     "nm_scale_features": (ctypes.c_int,
                           [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, _LATP, c_f64, c_ptr,
                            c_i64, c_ptr, c_ptr, c_size, c_ptr]),
+    "nm_multiscale_workspace_bytes": (c_size, [c_i64, c_i64, _LATP, c_i32]),
+    "nm_multiscale_features": (ctypes.c_int,
+                               [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, _LATP,
+                                ctypes.POINTER(c_f64), c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_size,
+                                c_ptr]),
     "nm_scale_neighbors": (ctypes.c_int,
                            [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, _LATP, c_f64, c_ptr, c_ptr,
                             c_ptr, c_ptr]),

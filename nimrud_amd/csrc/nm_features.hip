@@ -33,6 +33,7 @@ struct ScaleArgs {
     int64_t n_slots;         // entries of `order` (= nq, or the search size when queries are a prefix)
     int64_t qstride;
     const uint32_t* order;   // order[slot] = query row processed in sorted slot `slot`
+    int32_t direct;          // 1: `query` is already in slot order, (n_slots,3); rows go to order[slot]
     LatticeDev L;
     IndexDev I;
     double r2;               // radius * radius (fp64 product, as scipy forms it)
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         have = qi < A.nq;    // prefix mode: the sorted order also holds the non-query search rows
     }
     if (have) {
-        const double* p = A.query + (int64_t)qi * A.qstride;
+        const double* p = A.query + (A.direct ? slot : (int64_t)qi) * A.qstride;
         qx = p[0];
         qy = p[1];
         qz = p[2];
@@ -363,6 +364,8 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
     }
     lds_fence();
 
+    uint32_t m_n = 0, m_sx = 0, m_sy = 0, m_sz = 0, m_sxx = 0, m_sxy = 0, m_sxz = 0, m_syy = 0,
+             m_syz = 0, m_szz = 0;
     uint32_t passes = 0;
     for (;;) {
         const unsigned long long todo = __ballot(!done);
@@ -481,26 +484,35 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                 sxz += xb * i;
                 syz += cji * i;
             }
-            double out[4];
-            const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
-            const double uy = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
-            const double uz = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
-            nm_features_from_moments((double)n, (double)sx, (double)sy, (double)sz, (double)sxx,
-                                     (double)sxy, (double)sxz, (double)syy, (double)syz,
-                                     (double)szz, ux, uy, uz, (double)dmin, L.edge, out);
-            double* o = A.feat + (int64_t)qi * A.fstride;
-            o[0] = out[0];
-            o[1] = out[1];
-            o[2] = out[2];
-            o[3] = out[3];
-            const unsigned long long degenerate = __ballot(n < 2u);
-            if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
-                atomicAdd(&A.stats[0], (uint32_t)__popcll(degenerate));
+            // the ten integer moments wait in registers; the eigen-solve runs once, after the last
+            // pass, for all lanes together (an extra pass costs staging + this row walk only)
+            m_n = n; m_sx = sx; m_sy = sy; m_sz = sz; m_sxx = sxx; m_sxy = sxy; m_sxz = sxz;
+            m_syy = syy; m_syz = syz; m_szz = szz;
             done = true;
         }
         lds_fence();
     }
     if (passes > 1 && lane == 0) atomicAdd(&A.stats[1], passes - 1);
+
+    // ---- epilogue: features from the integer moments (features.py:21-57), one query per lane
+    const bool emit = have && !far;
+    if (emit) {
+        double out[4];
+        const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
+        const double uy = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
+        const double uz = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
+        nm_features_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
+                                 (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
+                                 (double)m_syz, (double)m_szz, ux, uy, uz, (double)dmin, L.edge, out);
+        double* o = A.feat + (int64_t)qi * A.fstride;
+        o[0] = out[0];
+        o[1] = out[1];
+        o[2] = out[2];
+        o[3] = out[3];
+    }
+    const unsigned long long degenerate = __ballot(emit && m_n < 2u);
+    if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
+        atomicAdd(&A.stats[0], (uint32_t)__popcll(degenerate));
 }
 
 // ---- generic kernel: any W, direct index lookups per lane (no staging).  slow path for unusual
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
     if (slot >= A.n_slots) return;
     const uint32_t qi = A.order[slot];
     if (qi >= A.nq) return;
-    const double* p = A.query + (int64_t)qi * A.qstride;
+    const double* p = A.query + (A.direct ? slot : (int64_t)qi) * A.qstride;
     const double qx = p[0], qy = p[1], qz = p[2];
     const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
     const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
@@ -602,6 +614,51 @@ static int candidate_width(double radius, double edge, int32_t* dmin)
     return 2 * (int32_t)m + 1;
 }
 
+// picks the kernel instance for (W, r/e) and launches it
+static void launch_scale_kernel(const ScaleArgs& A, const nm_lattice* lat, double radius, int W,
+                                hipStream_t s)
+{
+    const int blocks = (int)((A.n_slots + 63) / 64);
+    // static pruning of the candidate window is sound only while the rounding of cells and centres
+    // stays far below the 1e-4-cell padding of the bounds: 16 ulp of the largest coordinate the
+    // lattice can produce must be smaller than that.
+    double maxabs = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        const double lo = lat->min_corner[a];
+        const double hi = lo + ldexp(lat->edge, lat->widths[a]);
+        maxabs = fmax(maxabs, fmax(fabs(lo), fabs(hi)));
+    }
+    const bool prune = 16.0 * maxabs * 2.220446049250313e-16 < 1e-4 * lat->edge;
+    const double rho = radius / lat->edge;
+    const double rho2 = rho * rho;
+    const bool rho3 = prune && W == 7 && fabs(rho - 3.0) < 1e-9;
+    switch (W) {
+        case 3: k_scale_features<3, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, prune)); break;
+        case 5: k_scale_features<5, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, prune)); break;
+        case 7:
+            if (rho3) k_scale_features<7, true><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3);
+            else k_scale_features<7, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, prune));
+            break;
+        case 9: k_scale_features<9, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, prune)); break;
+        default: k_scale_features_generic<<<blocks, 64, 0, s>>>(A); break;
+    }
+}
+
+static int check_scale_args(nm_ctx* ctx, const char* who, const double* d_query, int64_t n_query,
+                            int64_t query_stride, const double* d_search, int64_t n_search,
+                            int64_t search_stride, const double* d_feat, int64_t feat_stride,
+                            const void* d_work)
+{
+    if (!d_search || n_search < 2 || search_stride < 3 || n_query < 0 || feat_stride < 4 || !d_work ||
+        n_search >= ((int64_t)1 << 31) || n_query >= ((int64_t)1 << 31))
+        NM_FAIL(ctx, NM_ERR_INVALID, "%s: bad arguments", who);
+    if (n_query > 0 && (!d_query || !d_feat || query_stride < 3))
+        NM_FAIL(ctx, NM_ERR_INVALID, "%s: bad query/feature arguments", who);
+    return NM_OK;
+}
+
+// ---- one scale, self-contained (sorts at this scale) ----------------------------------------------------
+
 struct ScaleLayout {
     size_t key_tmp, val_tmp, key_sorted, val_sorted;   // search cloud (and query cloud when shared)
     size_t qkey_tmp, qval_tmp, qkey_sorted, qval_sorted;
@@ -655,12 +712,10 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
                                  size_t work_bytes, void* stream)
 {
     if (!ctx) return NM_ERR_INVALID;
-    if (!d_search || n_search < 2 || search_stride < 3 || n_query < 0 || feat_stride < 4 ||
-        !d_work || n_search >= ((int64_t)1 << 31) || n_query >= ((int64_t)1 << 31))
-        NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_features: bad arguments");
-    if (n_query > 0 && (!d_query || !d_feat || query_stride < 3))
-        NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_features: bad query/feature arguments");
-    int rc = validate_lattice(ctx, lat);
+    int rc = check_scale_args(ctx, "nm_scale_features", d_query, n_query, query_stride, d_search,
+                              n_search, search_stride, d_feat, feat_stride, d_work);
+    if (rc) return rc;
+    rc = validate_lattice(ctx, lat);
     if (rc) return rc;
     if (!(radius >= 0.0)) NM_FAIL(ctx, NM_ERR_RADIUS, "radius must be non-negative");
     LatticeDev L = make_lattice_dev(lat);
@@ -681,6 +736,8 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)d_work;
 
+    // profile stages are [keys+sort | index | fused kernel]: four marks per call.  with a separate
+    // query cloud both sorts and the index are booked together under the first stage.
     nm_profile_mark(ctx, s);
     rc = nm_sort_cells(ctx, d_search, n_search, search_stride, L, (uint64_t*)(w + S.key_tmp),
                        (uint32_t*)(w + S.val_tmp), (uint64_t*)(w + S.key_sorted),
@@ -700,8 +757,6 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         if (rc) return rc;
         order = (const uint32_t*)(w + S.qval_sorted);
     }
-    // profile stages are [keys+sort | index | fused kernel]: four marks per call.  with a separate
-    // query cloud both sorts and the index are booked together under the first stage.
     if (!shared) nm_profile_mark(ctx, s);
     nm_profile_mark(ctx, s);
 
@@ -712,6 +767,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.n_slots = shared ? n_search : n_query;
         A.qstride = query_stride;
         A.order = order;
+        A.direct = 0;
         A.L = L;
         A.I = I;
         A.r2 = radius * radius;
@@ -720,36 +776,163 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.feat = d_feat;
         A.fstride = feat_stride;
         A.stats = I.counters + 8;
-        const int blocks = (int)((A.n_slots + 63) / 64);
-        // static pruning of the candidate window is sound only while the rounding of cells and
-        // centres stays far below the 1e-4-cell padding of the bounds: 16 ulp of the largest
-        // coordinate the lattice can produce must be smaller than that.
-        double maxabs = 0.0;
-        for (int a = 0; a < 3; ++a) {
-            const double lo = lat->min_corner[a];
-            const double hi = lo + ldexp(lat->edge, lat->widths[a]);
-            maxabs = fmax(maxabs, fmax(fabs(lo), fabs(hi)));
-        }
-        const bool prune = 16.0 * maxabs * 2.220446049250313e-16 < 1e-4 * lat->edge;
-        const double rho = radius / lat->edge;
-        const double rho2 = rho * rho;
-        const bool rho3 = prune && W == 7 && fabs(rho - 3.0) < 1e-9;
-        switch (W) {
-            case 3: k_scale_features<3, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, prune)); break;
-            case 5: k_scale_features<5, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, prune)); break;
-            case 7:
-                if (rho3) k_scale_features<7, true><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3);
-                else k_scale_features<7, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, prune));
-                break;
-            case 9: k_scale_features<9, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, prune)); break;
-            default: k_scale_features_generic<<<blocks, 64, 0, s>>>(A); break;
-        }
+        launch_scale_kernel(A, lat, radius, W, s);
     }
     nm_profile_mark(ctx, s);
     NM_HIP(ctx, hipGetLastError());
-    if (d_info) {
-        // {M, degenerate neighborhoods, extra passes, leaves}: widen the u32 counters on the device
-        k_publish_info<<<1, 64, 0, s>>>(I.counters, d_info);
+    if (d_info) k_publish_info<<<1, 64, 0, s>>>(I.counters, d_info);
+    return NM_OK;
+}
+
+// ---- the whole ladder: one spatial order for every scale ----------------------------------------------
+
+struct LadderLayout {
+    // per cloud: sort scratch, the order and the coordinates in that order
+    size_t s_key_tmp, s_val_tmp, s_key, s_order, s_xyz;
+    size_t q_key_tmp, q_val_tmp, q_key, q_order, q_xyz;
+    size_t sort_temp, sort_temp_bytes;
+    size_t index, index_bytes;
+    size_t total;
+};
+
+static void ladder_layout(int64_t nq, int64_t ns, const nm_lattice* lats, int n_scales, bool shared,
+                          LadderLayout* S)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off += align_up(bytes);
+        return at;
+    };
+    S->s_key_tmp = take((size_t)ns * 8);
+    S->s_val_tmp = take((size_t)ns * 4);
+    S->s_key = take((size_t)ns * 8);
+    S->s_order = take((size_t)ns * 4);
+    S->s_xyz = take((size_t)ns * 24);
+    if (!shared) {
+        S->q_key_tmp = take((size_t)nq * 8);
+        S->q_val_tmp = take((size_t)nq * 4);
+        S->q_key = take((size_t)nq * 8);
+        S->q_order = take((size_t)nq * 4);
+        S->q_xyz = take((size_t)nq * 24);
+    } else {
+        S->q_key_tmp = S->q_val_tmp = S->q_key = S->q_order = S->q_xyz = 0;
+    }
+    S->sort_temp_bytes = nm_sort_pairs_temp_bytes(ns > nq ? ns : nq);
+    S->sort_temp = take(S->sort_temp_bytes);
+    size_t index_bytes = 0;
+    for (int i = 0; i < n_scales; ++i) {
+        IndexLayout il;
+        nm_index_layout(make_lattice_dev(&lats[i]), ns, &il);
+        if (il.total > index_bytes) index_bytes = il.total;
+    }
+    S->index_bytes = index_bytes;
+    S->index = take(index_bytes);
+    S->total = off;
+}
+
+extern "C" size_t nm_multiscale_workspace_bytes(int64_t n_query, int64_t n_search,
+                                                const nm_lattice* lats, int32_t n_scales)
+{
+    if (!lats || n_scales < 1 || n_query < 0 || n_search < 1) return 0;
+    LadderLayout S;
+    ladder_layout(n_query > 0 ? n_query : 1, n_search, lats, n_scales, false, &S);
+    return S.total;
+}
+
+extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_t n_query,
+                                      int64_t query_stride, const double* d_search, int64_t n_search,
+                                      int64_t search_stride, const nm_lattice* lats,
+                                      const double* radii, int32_t n_scales, double* d_feat,
+                                      int64_t feat_stride, int64_t* d_info, void* d_work,
+                                      size_t work_bytes, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (n_scales < 0 || (n_scales > 0 && (!lats || !radii)))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: bad scale arguments");
+    if (n_scales == 0) return NM_OK;
+    if (feat_stride < 4 * (int64_t)n_scales)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: feat_stride < 4 * n_scales");
+    int rc = check_scale_args(ctx, "nm_multiscale_features", d_query, n_query, query_stride, d_search,
+                              n_search, search_stride, d_feat, feat_stride, d_work);
+    if (rc) return rc;
+    int finest = 0;
+    for (int i = 0; i < n_scales; ++i) {
+        rc = validate_lattice(ctx, &lats[i]);
+        if (rc) return rc;
+        if (!(radii[i] >= 0.0)) NM_FAIL(ctx, NM_ERR_RADIUS, "radius must be non-negative");
+        if (make_lattice_dev(&lats[i]).keybits > 64)
+            NM_FAIL(ctx, NM_ERR_LATTICE, "lattice too large for the device sort key");
+        int32_t dm;
+        if (candidate_width(radii[i], lats[i].edge, &dm) < 0)
+            NM_FAIL(ctx, NM_ERR_RADIUS, "radius/edge ratio %g is outside the supported range",
+                    radii[i] / lats[i].edge);
+        if (lats[i].edge < lats[finest].edge) finest = i;
+    }
+    const bool shared = (d_query == d_search && n_query <= n_search && n_query > 0 &&
+                         query_stride == search_stride);
+    LadderLayout S;
+    ladder_layout(n_query > 0 ? n_query : 1, n_search, lats, n_scales, shared, &S);
+    if (work_bytes < S.total)
+        NM_FAIL(ctx, NM_ERR_WORKSPACE, "nm_multiscale_features: workspace %zu < required %zu",
+                work_bytes, S.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)d_work;
+
+    // one spatial order per cloud, from the finest lattice of the ladder
+    const LatticeDev Lf = make_lattice_dev(&lats[finest]);
+    nm_profile_mark(ctx, s);   // first mark of scale 0: the order build is booked under its "keys"
+    rc = nm_order_build(ctx, d_search, n_search, search_stride, Lf, (uint64_t*)(w + S.s_key_tmp),
+                        (uint32_t*)(w + S.s_val_tmp), (uint64_t*)(w + S.s_key),
+                        (uint32_t*)(w + S.s_order), w + S.sort_temp, S.sort_temp_bytes,
+                        (double*)(w + S.s_xyz), s);
+    if (rc) return rc;
+    const uint32_t* q_order = (const uint32_t*)(w + S.s_order);
+    const double* q_xyz = (const double*)(w + S.s_xyz);
+    if (!shared && n_query > 0) {
+        rc = nm_order_build(ctx, d_query, n_query, query_stride, Lf, (uint64_t*)(w + S.q_key_tmp),
+                            (uint32_t*)(w + S.q_val_tmp), (uint64_t*)(w + S.q_key),
+                            (uint32_t*)(w + S.q_order), w + S.sort_temp, S.sort_temp_bytes,
+                            (double*)(w + S.q_xyz), s);
+        if (rc) return rc;
+        q_order = (const uint32_t*)(w + S.q_order);
+        q_xyz = (const double*)(w + S.q_xyz);
+    }
+
+    for (int i = 0; i < n_scales; ++i) {
+        const LatticeDev L = make_lattice_dev(&lats[i]);
+        int32_t dmin = 0;
+        const int W = candidate_width(radii[i], lats[i].edge, &dmin);
+        IndexLayout il;
+        nm_index_layout(L, n_search, &il);
+        if (i > 0) nm_profile_mark(ctx, s);
+        IndexDev I;
+        // marks the keys/index boundary itself
+        rc = nm_index_build_any(ctx, (const double*)(w + S.s_xyz), n_search, L,
+                                (uint64_t*)(w + S.s_key), il, w + S.index, &I, s);
+        if (rc) return rc;
+        nm_profile_mark(ctx, s);
+        if (n_query > 0) {
+            ScaleArgs A;
+            A.query = q_xyz;
+            A.nq = n_query;
+            A.n_slots = shared ? n_search : n_query;
+            A.qstride = 3;
+            A.order = q_order;
+            A.direct = 1;
+            A.L = L;
+            A.I = I;
+            A.r2 = radii[i] * radii[i];
+            A.dmin = dmin;
+            A.W = W;
+            A.feat = d_feat + 4 * i;
+            A.fstride = feat_stride;
+            A.stats = I.counters + 8;
+            launch_scale_kernel(A, &lats[i], radii[i], W, s);
+        }
+        nm_profile_mark(ctx, s);
+        NM_HIP(ctx, hipGetLastError());
+        if (d_info) k_publish_info<<<1, 64, 0, s>>>(I.counters, d_info + 4 * i);
     }
     return NM_OK;
 }

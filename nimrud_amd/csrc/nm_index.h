@@ -19,3 +19,15 @@ int nm_sort_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, c
 // hash table + leaves from the sorted keys of the search cloud
 int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const IndexLayout& lay,
                    void* index_mem, IndexDev* out, hipStream_t s);
+
+// whole-ladder path: one spatial order for all scales.
+// order[i] = original row of sorted slot i (sorted by the cell key of lattice L), sorted_xyz = the
+// coordinates in that order, (n,3) contiguous.
+int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const LatticeDev& L,
+                   uint64_t* key_tmp, uint32_t* val_tmp, uint64_t* key_sorted, uint32_t* order,
+                   void* sort_temp, size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
+
+// index of lattice L from a spatially coherent coordinate stream (no sort); key_buf is n u64 scratch
+int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
+                       uint64_t* key_buf, const IndexLayout& lay, void* index_mem, IndexDev* out,
+                       hipStream_t s);

@@ -542,3 +542,222 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
     *out = I;
     return NM_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// index build from a spatially coherent (but not sorted-at-this-scale) key stream.
+//
+// the whole-ladder path sorts the cloud once, by its cell keys at the finest scale, and keeps a copy of
+// the coordinates in that order.  at every other scale the keys of that stream are no longer sorted,
+// but neighbours in the stream are still neighbours in space, so runs of equal superblock / equal row
+// word are long.  duplicates are therefore squeezed out inside each wave (compare with the previous
+// key), and what is left goes through the hash table with atomics:
+//   k_index_insert   run heads CAS their superblock key into the table; a block's winners get leaf
+//                    numbers from ONE counter bump per block, zero their leaf and publish it
+//   k_index_bits_any run tails atomicOr the run's bits into the leaf; bits that were not set before
+//                    are the new voxels, which gives M without a sorted unique pass
+// ---------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_gather_xyz(const double* __restrict__ xyz, int64_t n,
+                                                    int64_t stride,
+                                                    const uint32_t* __restrict__ order,
+                                                    double* __restrict__ out)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = xyz + (int64_t)order[i] * stride;
+    out[i * 3 + 0] = p[0];
+    out[i * 3 + 1] = p[1];
+    out[i * 3 + 2] = p[2];
+}
+
+__global__ __launch_bounds__(256) void k_cell_keys_only(const double* __restrict__ xyz, int64_t n,
+                                                        int64_t stride, LatticeDev L,
+                                                        uint64_t* __restrict__ key)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = xyz + i * stride;
+    int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
+    int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
+    int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
+    cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
+    cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
+    cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
+    key[i] = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
+}
+
+__global__ __launch_bounds__(256) void k_index_insert(const uint64_t* __restrict__ key, int64_t n,
+                                                      IndexDev I)
+{
+    __shared__ uint32_t won_slot[INDEX_CHUNK];
+    __shared__ uint32_t won_count;
+    __shared__ uint32_t leaf_base;
+    if (threadIdx.x == 0) won_count = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
+    for (int it = 0; it < INDEX_ITERS; ++it) {
+        const int64_t i = wave_lo + it * 64 + lane;
+        if (wave_lo + it * 64 >= n) break;
+        const bool valid = i < n;
+        const uint64_t sb = valid ? (key[i] >> NM_LOCAL_BITS) : 0ull;
+        // only the first key of a run of equal superblocks goes to the table
+        const uint64_t prev = (valid && i > 0) ? (key[i - 1] >> NM_LOCAL_BITS) : ~sb;
+        if (valid && sb != prev) {
+            uint32_t slot = nm_hash64(sb) & I.hash_mask;
+            for (;;) {
+                const unsigned long long seen =
+                    atomicCAS((unsigned long long*)&I.hash_key[slot],
+                              (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
+                if (seen == NM_HASH_EMPTY) {
+                    won_slot[atomicAdd(&won_count, 1u)] = slot;
+                    break;
+                }
+                if (seen == sb) break;
+                slot = (slot + 1) & I.hash_mask;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = won_count;
+    if (total == 0) return;
+    if (threadIdx.x == 0) leaf_base = atomicAdd(&I.counters[0], total);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
+        const uint32_t idx = leaf_base + t;
+        if (idx >= I.leaf_capacity) {
+            I.counters[2] = 1u;
+            continue;
+        }
+        uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
+#pragma unroll
+        for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
+        I.hash_val[won_slot[t]] = idx;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restrict__ key, int64_t n,
+                                                        IndexDev I)
+{
+    __shared__ uint32_t wcells[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
+    uint32_t cells = 0;
+    for (int it = 0; it < INDEX_ITERS; ++it) {
+        const int64_t i = wave_lo + it * 64 + lane;
+        if (wave_lo + it * 64 >= n) break;
+        const bool valid = i < n;
+        const uint64_t k = valid ? key[i] : 0ull;
+        const uint64_t prev = __shfl_up(k, 1);
+        // runs are delimited inside this group of 64 only: lane 0 always starts one
+        const bool row_head = lane == 0 || (k >> NM_SBX_BITS) != (prev >> NM_SBX_BITS) || !valid;
+        const bool sb_head = lane == 0 || (k >> NM_LOCAL_BITS) != (prev >> NM_LOCAL_BITS) || !valid;
+        const unsigned long long below = (2ull << lane) - 1ull;
+        const unsigned long long sbm = __ballot(sb_head);
+        int32_t leaf = -1;
+        if (sb_head && valid) leaf = nm_hash_find(I, k >> NM_LOCAL_BITS);
+        leaf = __shfl(leaf, 63 - __clzll((long long)(sbm & below)));
+        const unsigned long long rowm = __ballot(row_head);
+        const int seg_start = 63 - __clzll((long long)(rowm & below));
+        uint32_t bits = valid ? (1u << ((uint32_t)k & 31u)) : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t other = __shfl_up(bits, off);
+            if (lane - off >= seg_start) bits |= other;
+        }
+        const bool tail = valid && (lane == 63 || ((rowm >> (lane + 1)) & 1ull) || i + 1 >= n);
+        uint32_t fresh = 0;
+        if (tail && leaf >= 0) {
+            const uint32_t local = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
+            const uint32_t old =
+                atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)], bits);
+            fresh = (uint32_t)__popc(bits & ~old);      // voxels nobody had set before
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
+        cells += fresh;
+    }
+    if (lane == 0) wcells[w] = cells;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = wcells[0] + wcells[1] + wcells[2] + wcells[3];
+        if (t) atomicAdd(&I.counters[1], t);
+    }
+}
+
+// 3-D Morton (Z-order) code of a cell, 21 bits per axis.  used only for the one-time spatial sort of the
+// whole-ladder path: a Z-order run of points is compact in all three axes at EVERY coarser scale,
+// which keeps the boxes the search kernel stages small (a column-major order scatters vertical
+// structures - poles, facades - over the whole slab).
+__device__ __forceinline__ uint64_t nm_spread3(uint32_t v)
+{
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_order_keys(const double* __restrict__ xyz, int64_t n,
+                                                    int64_t stride, LatticeDev L, int morton,
+                                                    uint64_t* __restrict__ key,
+                                                    uint32_t* __restrict__ val)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = xyz + i * stride;
+    int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
+    int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
+    int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
+    cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
+    cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
+    cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
+    key[i] = morton ? (nm_spread3((uint32_t)cx) | (nm_spread3((uint32_t)cy) << 1) |
+                       (nm_spread3((uint32_t)cz) << 2))
+                    : nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
+    val[i] = (uint32_t)i;
+}
+
+int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const LatticeDev& L,
+                   uint64_t* key_tmp, uint32_t* val_tmp, uint64_t* key_sorted, uint32_t* order,
+                   void* sort_temp, size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s)
+{
+    int wmax = L.wx > L.wy ? L.wx : L.wy;
+    if (L.wz > wmax) wmax = L.wz;
+    const int morton = wmax <= 21;
+    const unsigned bits = morton ? (unsigned)(3 * wmax) : (unsigned)L.keybits;
+    k_order_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, morton, key_tmp,
+                                                       val_tmp);
+    NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp,
+                                          order, (size_t)n, 0, bits, s));
+    k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
+                       uint64_t* key_buf, const IndexLayout& lay, void* index_mem, IndexDev* out,
+                       hipStream_t s)
+{
+    char* w = (char*)index_mem;
+    IndexDev I;
+    I.hash_key = (uint64_t*)w;      w += lay.hash_key_bytes;
+    I.hash_val = (uint32_t*)w;      w += lay.hash_val_bytes;
+    I.leaf = (uint32_t*)w;          w += lay.leaf_bytes;
+    I.counters = (uint32_t*)w;
+    I.hash_mask = lay.hash_capacity - 1;
+    I.leaf_capacity = lay.leaf_capacity;
+    NM_HIP(ctx, hipMemsetAsync(I.hash_key, 0xFF, (size_t)lay.hash_capacity * 8, s));
+    NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
+    k_cell_keys_only<<<(int)((n + 255) / 256), 256, 0, s>>>(sorted_xyz, n, 3, L, key_buf);
+    nm_profile_mark(ctx, s);      // end of the "keys" stage, start of the "index" stage
+    const int blocks = (int)((n + INDEX_CHUNK - 1) / INDEX_CHUNK);
+    k_index_insert<<<blocks, 256, 0, s>>>(key_buf, n, I);
+    k_index_bits_any<<<blocks, 256, 0, s>>>(key_buf, n, I);
+    NM_HIP(ctx, hipGetLastError());
+    *out = I;
+    return NM_OK;
+}

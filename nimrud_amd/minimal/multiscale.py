@@ -63,11 +63,35 @@ def _scale_into(rt, query, search, shared, lo, hi, edge_length, radius, out_view
         _device.ptr(work), work.numel(), rt.stream()))
 
 
+def _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info):
+    """enqueue the whole ladder in one library call (nm_multiscale_features): the cloud is sorted
+    once, every scale's index is built from that order."""
+    from nimrud_amd import _ffi
+    n_scales = len(edge_lengths)
+    lats = (_ffi.NmLattice * n_scales)()
+    for s, e in enumerate(edge_lengths):
+        vf = geometry.VoxelFilter.from_bounds(lo, hi, e, device=rt.device)
+        ctypes.memmove(ctypes.byref(lats[s]), ctypes.byref(vf.nm_lattice),
+                       ctypes.sizeof(_ffi.NmLattice))
+    rad = (ctypes.c_double * n_scales)(*[float(r) for r in radii])
+    nq, ns = query.shape[0], search.shape[0]
+    nbytes = rt.lib.nm_multiscale_workspace_bytes(nq, ns, lats, n_scales)
+    work = rt.workspace(nbytes)
+    qt = search if shared else query
+    rt.check(rt.lib.nm_multiscale_features(
+        rt.ctx, _device.ptr(qt), nq, _device.row_stride(qt),
+        _device.ptr(search), ns, _device.row_stride(search), lats, rad, n_scales,
+        _device.ptr(out), int(out.stride(0)), _device.ptr(info),
+        _device.ptr(work), work.numel(), rt.stream()))
+
+
 def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, strict=False,
-                return_info=False, out=None):
+                return_info=False, out=None, per_scale=False):
     """process_single_core for clouds resident in HBM: torch GPU tensors in, (Nq, 4*S) fp64 GPU tensor
     out.  nothing crosses PCIe except six doubles (the search cloud's extrema) and, when strict or
-    return_info, 4 counters per scale."""
+    return_info, 4 counters per scale.
+    the ladder normally runs as ONE library call that sorts the cloud once for all scales;
+    verbose=True or per_scale=True runs one self-contained call per scale instead (same numbers)."""
     assert len(edge_lengths) == len(radii), \
         "edge_lengths and radii should be equal-length sequences."
     shared = query_cloud is search_cloud
@@ -87,7 +111,12 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
 
     outer_start = time.perf_counter()
     lo, hi = _device.cloud_bounds(rt, search)
-    for s, (this_edge, this_radius) in enumerate(zip(edge_lengths, radii)):
+    if not (verbose or per_scale):
+        _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info)
+        edge_lengths_loop = []
+    else:
+        edge_lengths_loop = list(zip(edge_lengths, radii))
+    for s, (this_edge, this_radius) in enumerate(edge_lengths_loop):
         inner_start = time.perf_counter()
         _scale_into(rt, query, search, shared, lo, hi, this_edge, this_radius,
                     out[:, 4 * s:4 * s + 4], info[s])

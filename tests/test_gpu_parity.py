@@ -375,3 +375,25 @@ def test_two_ranks_share_one_gpu_hip_backend():
         out, received = results[rank]
         assert np.array_equal(out, whole[parts[rank]])       # bit-identical
         assert 0 < received < len(points) - len(parts[rank])
+
+
+# ---- the one-sort ladder against the per-scale path ---------------------------------------------------
+
+def test_ladder_call_is_bit_identical_to_per_scale_calls():
+    pts, _ = synth.scene_cloud(150000, extent=25.0, n_poles=30, n_spheres=8, seed=101)
+    edges = [0.40, 0.05, 0.10, 0.80, 0.20]               # caller order, finest not first
+    radii = [1.20, 0.15, 0.30, 2.40, 0.60]
+    dev = torch.from_numpy(pts).cuda()
+    a, ia = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
+    b, ib = multiscale.process_gpu(dev, dev, edges, radii, return_info=True, per_scale=True)
+    assert torch.equal(a, b)
+    for x, y in zip(ia, ib):
+        assert x.voxels == y.voxels and x.degenerate == y.degenerate and x.leaves == y.leaves
+    # separate query cloud, partly outside
+    rs = np.random.RandomState(102)
+    query = torch.from_numpy(rs.rand(20000, 3) * 30.0 - 2.5).cuda()
+    c = multiscale.process_gpu(query, dev, edges, radii)
+    d = multiscale.process_gpu(query, dev, edges, radii, per_scale=True)
+    assert torch.equal(c, d)
+    want = oracle.process_fast(query.cpu().numpy(), pts, edges[:2], radii[:2])
+    assert_features_close(c.cpu().numpy()[:, :8], want, pts)
