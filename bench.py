@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3_scene_10m")
     ap.add_argument("--points", type=int, default=None, help="points per GPU (default: the config's)")
+    ap.add_argument("--overlap", type=int, default=None,
+                    help="nm_set_overlap value (0 = sequential stages, 1 = default pipelining)")
     ap.add_argument("--cpu-sample", type=int, default=150000,
                     help="points of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
@@ -103,6 +105,8 @@ def main():
     cloud = torch.from_numpy(points).to(dev)
     n_scales = len(edges)
     rt = nm_device.get_runtime(dev)
+    if args.overlap is not None:
+        rt.check(rt.lib.nm_set_overlap(rt.ctx, args.overlap))
 
     if world > 1:
         from nimrud_amd import parallel

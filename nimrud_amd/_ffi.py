@@ -49,6 +49,7 @@ SIGNATURES = {
     "nm_last_error": (ctypes.c_char_p, [c_ptr]),
     "nm_abi_version": (ctypes.c_int, []),
     "nm_profile_begin": (ctypes.c_int, [c_ptr]),
+    "nm_set_overlap": (ctypes.c_int, [c_ptr, ctypes.c_int]),
     "nm_profile_end": (ctypes.c_int, [c_ptr, ctypes.POINTER(c_f64 * 4), ctypes.POINTER(c_i64)]),
     "nm_bounds": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "nm_voxelize_workspace_bytes": (c_size, [c_i64]),

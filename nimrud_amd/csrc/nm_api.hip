@@ -27,7 +27,18 @@ extern "C" void nm_destroy(nm_ctx* ctx)
 {
     if (!ctx) return;
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->sync_events) (void)hipEventDestroy(e);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     delete ctx;
+}
+
+extern "C" int nm_set_overlap(nm_ctx* ctx, int enabled)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    ctx->overlap = enabled != 0;
+    // values above 1 also set how many fused-kernel workgroups per SIMD run beside a build (tuning)
+    if (enabled >= 2 && enabled <= 8) ctx->ladder_waves = enabled;
+    return NM_OK;
 }
 
 extern "C" int nm_profile_begin(nm_ctx* ctx)

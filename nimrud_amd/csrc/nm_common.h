@@ -17,6 +17,12 @@ struct nm_ctx {
     bool profiling = false;
     std::vector<hipEvent_t> events;
     size_t events_used = 0;
+    // whole-ladder pipelining: the index of scale i+1 is built on `aux` while the fused kernel of
+    // scale i runs on the caller's stream (nm_set_overlap)
+    bool overlap = false;        // measured: the long kernel starves the build stream; no gain yet
+    int ladder_waves = 5;        // fused-kernel workgroups per SIMD while a build runs beside it
+    hipStream_t aux = nullptr;
+    std::vector<hipEvent_t> sync_events;
 };
 
 // next profiling event recorded on `s`, or a no-op when profiling is off

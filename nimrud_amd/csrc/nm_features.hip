@@ -616,9 +616,14 @@ static int candidate_width(double radius, double edge, int32_t* dmin)
 
 // picks the kernel instance for (W, r/e) and launches it
 static void launch_scale_kernel(const ScaleArgs& A, const nm_lattice* lat, double radius, int W,
-                                hipStream_t s)
+                                hipStream_t s, int num_cus, int waves_per_simd)
 {
+    // one workgroup per 64-query batch: the hardware dispatcher balances the uneven batches (waves
+    // that need several passes) better than a persistent grid did (measured: persistent -17 %)
     const int blocks = (int)((A.n_slots + 63) / 64);
+    const int generic_blocks = blocks;
+    (void)num_cus;
+    (void)waves_per_simd;
     // static pruning of the candidate window is sound only while the rounding of cells and centres
     // stays far below the 1e-4-cell padding of the bounds: 16 ulp of the largest coordinate the
     // lattice can produce must be smaller than that.
@@ -640,7 +645,7 @@ static void launch_scale_kernel(const ScaleArgs& A, const nm_lattice* lat, doubl
             else k_scale_features<7, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, prune));
             break;
         case 9: k_scale_features<9, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, prune)); break;
-        default: k_scale_features_generic<<<blocks, 64, 0, s>>>(A); break;
+        default: k_scale_features_generic<<<generic_blocks, 64, 0, s>>>(A); break;
     }
 }
 
@@ -776,7 +781,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.feat = d_feat;
         A.fstride = feat_stride;
         A.stats = I.counters + 8;
-        launch_scale_kernel(A, lat, radius, W, s);
+        launch_scale_kernel(A, lat, radius, W, s, ctx->num_cus, 6);
     }
     nm_profile_mark(ctx, s);
     NM_HIP(ctx, hipGetLastError());
@@ -791,7 +796,8 @@ struct LadderLayout {
     size_t s_key_tmp, s_val_tmp, s_key, s_order, s_xyz;
     size_t q_key_tmp, q_val_tmp, q_key, q_order, q_xyz;
     size_t sort_temp, sort_temp_bytes;
-    size_t index, index_bytes;
+    size_t key2;                 // second key buffer (the first is s_key) for the pipelined build
+    size_t index[2], index_bytes;
     size_t total;
 };
 
@@ -827,8 +833,20 @@ static void ladder_layout(int64_t nq, int64_t ns, const nm_lattice* lats, int n_
         if (il.total > index_bytes) index_bytes = il.total;
     }
     S->index_bytes = index_bytes;
-    S->index = take(index_bytes);
+    S->key2 = take((size_t)ns * 8);
+    S->index[0] = take(index_bytes);
+    S->index[1] = take(index_bytes);
     S->total = off;
+}
+
+static hipEvent_t ladder_event(nm_ctx* ctx, size_t i)
+{
+    while (ctx->sync_events.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        ctx->sync_events.push_back(e);
+    }
+    return ctx->sync_events[i];
 }
 
 extern "C" size_t nm_multiscale_workspace_bytes(int64_t n_query, int64_t n_search,
@@ -899,18 +917,53 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         q_xyz = (const double*)(w + S.q_xyz);
     }
 
+    // pipelining: with overlap on (and profiling of the stages off) the index of scale i is built on
+    // the auxiliary stream into buffer i%2 while the caller's stream runs the kernel of scale i-1.
+    const bool overlap = ctx->overlap && n_scales > 1;
+    hipStream_t build = s;
+    if (overlap) {
+        if (!ctx->aux) {
+            // highest priority: the build kernels are short and memory/atomic bound; they must get
+            // dispatched between the workgroups of the long VALU-bound kernel, not behind them
+            int least = 0, greatest = 0;
+            NM_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            NM_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, greatest));
+        }
+        build = ctx->aux;
+        hipEvent_t ordered = ladder_event(ctx, 0);
+        if (!ordered) NM_FAIL(ctx, NM_ERR_HIP, "could not create a HIP event");
+        NM_HIP(ctx, hipEventRecord(ordered, s));
+        NM_HIP(ctx, hipStreamWaitEvent(build, ordered, 0));
+    }
+    uint64_t* key_buf[2] = {(uint64_t*)(w + S.s_key), (uint64_t*)(w + S.key2)};
     for (int i = 0; i < n_scales; ++i) {
         const LatticeDev L = make_lattice_dev(&lats[i]);
         int32_t dmin = 0;
         const int W = candidate_width(radii[i], lats[i].edge, &dmin);
         IndexLayout il;
         nm_index_layout(L, n_search, &il);
-        if (i > 0) nm_profile_mark(ctx, s);
+        const int b = overlap ? (i & 1) : 0;
+        if (overlap && i >= 2) {
+            // buffer b was last read by the kernel of scale i-2
+            NM_HIP(ctx, hipStreamWaitEvent(build, ladder_event(ctx, 1 + 2 * (i - 2) + 1), 0));
+        }
+        if (!overlap && i > 0) nm_profile_mark(ctx, s);
+        const bool was_profiling = ctx->profiling;
+        if (overlap) ctx->profiling = false;     // no stage marks on the auxiliary stream
         IndexDev I;
-        // marks the keys/index boundary itself
-        rc = nm_index_build_any(ctx, (const double*)(w + S.s_xyz), n_search, L,
-                                (uint64_t*)(w + S.s_key), il, w + S.index, &I, s);
+        rc = nm_index_build_any(ctx, (const double*)(w + S.s_xyz), n_search, L, key_buf[b], il,
+                                w + S.index[b], &I, build);
+        ctx->profiling = was_profiling;
         if (rc) return rc;
+        if (overlap) {
+            hipEvent_t built = ladder_event(ctx, 1 + 2 * i);
+            if (!built) NM_FAIL(ctx, NM_ERR_HIP, "could not create a HIP event");
+            NM_HIP(ctx, hipEventRecord(built, build));
+            NM_HIP(ctx, hipStreamWaitEvent(s, built, 0));
+            // keep four marks per scale: stages other than the kernel read as zero
+            if (i > 0) nm_profile_mark(ctx, s);
+            nm_profile_mark(ctx, s);
+        }
         nm_profile_mark(ctx, s);
         if (n_query > 0) {
             ScaleArgs A;
@@ -928,11 +981,16 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
             A.feat = d_feat + 4 * i;
             A.fstride = feat_stride;
             A.stats = I.counters + 8;
-            launch_scale_kernel(A, &lats[i], radii[i], W, s);
+            launch_scale_kernel(A, &lats[i], radii[i], W, s, ctx->num_cus, overlap ? ctx->ladder_waves : 6);
         }
         nm_profile_mark(ctx, s);
         NM_HIP(ctx, hipGetLastError());
         if (d_info) k_publish_info<<<1, 64, 0, s>>>(I.counters, d_info + 4 * i);
+        if (overlap) {
+            hipEvent_t ran = ladder_event(ctx, 1 + 2 * i + 1);
+            if (!ran) NM_FAIL(ctx, NM_ERR_HIP, "could not create a HIP event");
+            NM_HIP(ctx, hipEventRecord(ran, s));
+        }
     }
     return NM_OK;
 }

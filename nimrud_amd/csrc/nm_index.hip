@@ -607,6 +607,14 @@ __global__ __launch_bounds__(256) void k_index_insert(const uint64_t* __restrict
         if (valid && sb != prev) {
             uint32_t slot = nm_hash64(sb) & I.hash_mask;
             for (;;) {
+                // a plain look first: once a superblock is in the table every later run of it costs
+                // a (cached) load instead of an atomic.  a stale "empty" only means we try the CAS.
+                const uint64_t peek = I.hash_key[slot];
+                if (peek == sb) break;
+                if (peek != NM_HASH_EMPTY) {
+                    slot = (slot + 1) & I.hash_mask;
+                    continue;
+                }
                 const unsigned long long seen =
                     atomicCAS((unsigned long long*)&I.hash_key[slot],
                               (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
@@ -670,9 +678,13 @@ __global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restri
         uint32_t fresh = 0;
         if (tail && leaf >= 0) {
             const uint32_t local = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
-            const uint32_t old =
-                atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)], bits);
-            fresh = (uint32_t)__popc(bits & ~old);      // voxels nobody had set before
+            uint32_t* word = &I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)];
+            // a plain look first: at coarse scales most runs find their voxels already set (a stale
+            // value can only cause a redundant atomic, never a missed one)
+            if ((*word & bits) != bits) {
+                const uint32_t old = atomicOr(word, bits);
+                fresh = (uint32_t)__popc(bits & ~old);  // voxels nobody had set before
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
