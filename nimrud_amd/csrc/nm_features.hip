@@ -170,18 +170,28 @@ __device__ __forceinline__ void nm_features_from_moments(
     out[3] = l1 * inv_tr;
 }
 
-__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+// wave-wide min / max of an int32 with DPP row operations (6 VALU instructions + a readlane) instead
+// of 6 rounds through the LDS crossbar: quad swaps, half-row and row mirrors leave every row of 16
+// lanes holding its own result, row_bcast15 / row_bcast31 fold the four rows into lane 63.
+template <bool IS_MIN>
+__device__ __forceinline__ int32_t wave_reduce_i32(int32_t v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
+#define NM_STEP(ctrl, rowmask)                                                              \
+    {                                                                                       \
+        const int32_t o = __builtin_amdgcn_update_dpp(v, v, ctrl, rowmask, 0xF, false);     \
+        v = IS_MIN ? min(v, o) : max(v, o);                                                 \
+    }
+    NM_STEP(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    NM_STEP(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    NM_STEP(0x141, 0xF)   // row_half_mirror
+    NM_STEP(0x140, 0xF)   // row_mirror
+    NM_STEP(0x142, 0xA)   // row_bcast15 into rows 1 and 3
+    NM_STEP(0x143, 0xC)   // row_bcast31 into rows 2 and 3
+#undef NM_STEP
+    return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) { return wave_reduce_i32<true>(v); }
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) { return wave_reduce_i32<false>(v); }
 
 __device__ __forceinline__ void lds_fence()
 {
@@ -398,15 +408,21 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         const bool sel = !done && hx + dmin >= ox && hx + dmax < ox + 64 && hy + dmin >= oy &&
                          hy + dmax < oy + ey && hz + dmin >= oz && hz + dmax < oz + ez;
 
-        // ---- stage: leaf numbers of the box's superblocks
+        // ---- stage: leaf numbers of the box's superblocks (integer divisions by wave-uniform small
+        //      numbers are done with a 20-bit reciprocal: exact for operands below 2^10)
         const int32_t sbx0 = ox >> NM_SBX_BITS, sby0 = oy >> NM_SBY_BITS, sbz0 = oz >> NM_SBZ_BITS;
         const int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - sby0 + 1;
         const int32_t nsz = ((oz + ez - 1) >> NM_SBZ_BITS) - sbz0 + 1;
         const int32_t nsb = 3 * nsy * nsz;
+        const uint32_t inv_nsy = ((1u << 20) + (uint32_t)nsy - 1u) / (uint32_t)nsy;
+        const uint32_t inv_ey = ((1u << 20) + (uint32_t)ey - 1u) / (uint32_t)ey;
 #pragma nounroll
         for (int32_t t = lane; t < nsb; t += 64) {
-            int32_t ix = t % 3, iy = (t / 3) % nsy, iz = t / (3 * nsy);
-            int32_t sx = sbx0 + ix, sy = sby0 + iy, sz = sbz0 + iz;
+            const uint32_t t3 = ((uint32_t)t * 0x5556u) >> 16;        // t / 3 for t < 2^15
+            const int32_t ix = t - 3 * (int32_t)t3;
+            const uint32_t iz = (t3 * inv_nsy) >> 20;                  // t3 / nsy
+            const int32_t iy = (int32_t)t3 - (int32_t)iz * nsy;
+            int32_t sx = sbx0 + ix, sy = sby0 + iy, sz = sbz0 + (int32_t)iz;
             bool ok = sx >= 0 && sy >= 0 && sz >= 0 && sx < (1 << L.bx) && sy < (1 << L.by) &&
                       sz < (1 << L.bz);
             sbt[t] = ok ? nm_hash_find(A.I, nm_sb_key((uint32_t)sx, (uint32_t)sy, (uint32_t)sz, L))
@@ -418,7 +434,8 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         const uint32_t sh = (uint32_t)(ox & 31);
 #pragma nounroll
         for (int32_t rr = lane; rr < nrows; rr += 64) {
-            int32_t y = oy + rr % ey, z = oz + rr / ey;
+            const int32_t rz = (int32_t)(((uint32_t)rr * inv_ey) >> 20);   // rr / ey (rr < 512)
+            const int32_t y = oy + (rr - rz * ey), z = oz + rz;
             int32_t t0 = (((z >> NM_SBZ_BITS) - sbz0) * nsy + ((y >> NM_SBY_BITS) - sby0)) * 3;
             uint32_t wofs = (uint32_t)((z & 7) * 8 + (y & 7));
             int32_t l0 = sbt[t0], l1 = sbt[t0 + 1], l2 = sbt[t0 + 2];
