@@ -227,16 +227,36 @@ struct RowBound {
 constexpr double nm_sq(double v) { return v * v; }
 constexpr double nm_pos(double v) { return v > 0.0 ? v : 0.0; }
 
+// |d - u| for a cell offset d and a query offset u in [-eta, 1/2 + eta] (mirrored axes) or in
+// [-1/2 - eta, 1/2 + eta] (x): smallest and largest possible value
+constexpr double nm_abs(double v) { return v < 0.0 ? -v : v; }
+constexpr double nm_max(double a, double b) { return a > b ? a : b; }
+constexpr double nm_near(double d, double ulo, double uhi)
+{
+    // distance from d to the interval [ulo, uhi]
+    return d < ulo ? ulo - d : (d > uhi ? d - uhi : 0.0);
+}
+constexpr double nm_far(double d, double ulo, double uhi)
+{
+    return nm_max(nm_abs(d - ulo), nm_abs(d - uhi));
+}
+
+// the kernel mirrors every lane's window in y and z so that the query lies in the upper half of its
+// home cell on those axes (u in [0, 1/2]); x stays two-sided (mirroring x would cost a bit reversal
+// of every occupancy row).  rows are indexed in that mirrored frame.
 constexpr RowBound nm_row_bound(int W, double rho2, int j, int k)
 {
     const int c = (W - 1) / 2;
     const double eta = 1e-4;
-    const double ady = (double)(j > c ? j - c : c - j), adz = (double)(k > c ? k - c : c - k);
+    const double dy = (double)(j - c), dz = (double)(k - c);
+    const double ny = nm_near(dy, -eta, 0.5 + eta), fy = nm_far(dy, -eta, 0.5 + eta);
+    const double nz = nm_near(dz, -eta, 0.5 + eta), fz = nm_far(dz, -eta, 0.5 + eta);
     int a = -1, b = -1;
     for (int ax = 0; ax <= c; ++ax) {
-        const double far2 = nm_sq(ax + 0.5 + eta) + nm_sq(ady + 0.5 + eta) + nm_sq(adz + 0.5 + eta);
-        const double near2 = nm_sq(nm_pos(ax - 0.5 - eta)) + nm_sq(nm_pos(ady - 0.5 - eta)) +
-                             nm_sq(nm_pos(adz - 0.5 - eta));
+        const double fx = nm_far((double)ax, -0.5 - eta, 0.5 + eta);
+        const double nx = nm_near((double)ax, -0.5 - eta, 0.5 + eta);
+        const double far2 = nm_sq(fx) + nm_sq(fy) + nm_sq(fz);
+        const double near2 = nm_sq(nx) + nm_sq(ny) + nm_sq(nz);
         if (far2 <= rho2 * (1.0 - 1e-9) && a == ax - 1) a = ax;
         if (near2 <= rho2 * (1.0 + 1e-9)) b = ax;
     }
@@ -323,19 +343,27 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         o[3] = 0.0;
     }
 
+    // reflect the window in y and z so that the query is in the upper half of its home cell there
+    // (population, centroid distance and eigenvalues are invariant under these reflections)
+    const double uy_home = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
+    const double uz_home = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
+    const int32_t sgn_y = uy_home < 0.0 ? -1 : 1;
+    const int32_t sgn_z = uz_home < 0.0 ? -1 : 1;
+
     // ---- phase A (once per wave): the inside/outside bit of every candidate that needs a test, as
     //      W-bit row masks packed ROWS_PER_REG to a register.  independent of the occupancy.
     uint32_t inside[MASK_REGS];
     {
         // squared coordinate differences to the W candidate centres per axis (bit-identical centres)
+        // index i of the y and z tables is in the lane's mirrored frame: cell = home + sgn*(i - C)
         double dx2[W], dy2[W], dz2[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) {
             double d = qx - nm_centre(hx + dmin + i, L.min_x, L.edge, L.half_edge);
             dx2[i] = d * d;
-            d = qy - nm_centre(hy + dmin + i, L.min_y, L.edge, L.half_edge);
+            d = qy - nm_centre(hy + sgn_y * (i - C), L.min_y, L.edge, L.half_edge);
             dy2[i] = d * d;
-            d = qz - nm_centre(hz + dmin + i, L.min_z, L.edge, L.half_edge);
+            d = qz - nm_centre(hz + sgn_z * (i - C), L.min_z, L.edge, L.half_edge);
             dz2[i] = d * d;
         }
 #pragma unroll
@@ -452,7 +480,9 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         //      table reads, per j; rows nobody occupies add the table's zero entry.
         if (sel) {
             const int32_t rx = hx + dmin - ox;
-            const int32_t rbase = (hz + dmin - oz) * ey + (hy + dmin - oy);
+            // row of the home cell, and the lane's signed strides through the mirrored window
+            const int32_t rhome = (hz - oz) * ey + (hy - oy);
+            const int32_t step_z = sgn_z * ey, step_y = sgn_y;
             uint32_t aj[W], bk[W], cj[W];
 #pragma unroll
             for (int i = 0; i < W; ++i) aj[i] = bk[i] = cj[i] = 0u;
@@ -465,7 +495,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                 uint32_t valid[W];
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    const uint64_t row = rows[rbase + k * ey + j];
+                    const uint64_t row = rows[rhome + (k - C) * step_z + (j - C) * step_y];
                     const int r = j * W + k;
                     const uint32_t in =
                         (inside[r / ROWS_PER_REG] >> ((r % ROWS_PER_REG) * W)) & ((1u << W) - 1u);
@@ -515,9 +545,10 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
     const bool emit = have && !far;
     if (emit) {
         double out[4];
+        // the moments are in the mirrored frame; so must be the query's offset from its home centre
         const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
-        const double uy = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
-        const double uz = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
+        const double uy = fabs(uy_home);
+        const double uz = fabs(uz_home);
         nm_features_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
                                  (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
                                  (double)m_syz, (double)m_szz, ux, uy, uz, (double)dmin, L.edge, out);
