@@ -26,6 +26,24 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "r1_final_traffic.json")
+
+
+def measured_traffic(points_per_gpu):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (tools/pmc_summary.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
+    doubled as the gfx950 note in MI355X_MICROARCH.md prescribes and as calibrated on k_cell_keys_only).
+    only valid for the configuration it was collected on; None otherwise."""
+    if points_per_gpu != 10_000_000 or not os.path.exists(TRAFFIC_FILE):
+        return None
+    try:
+        data = json.load(open(TRAFFIC_FILE))
+        for name, rec in data["kernels"].items():
+            if name.startswith("k_scale_features<7"):
+                return rec.get("hbm_bytes_per_launch_mean")
+    except Exception:   # noqa: BLE001
+        return None
+    return None
 
 
 def parse_args():
@@ -198,7 +216,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": measured_traffic(nq) if world == 1 else None,
+                "traffic_source": "profiles/r1_final_traffic.json (rocprofv3 --pmc, separate passes)",
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms_avg": k_ms,
             },
