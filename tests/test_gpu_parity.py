@@ -397,3 +397,66 @@ def test_ladder_call_is_bit_identical_to_per_scale_calls():
     assert torch.equal(c, d)
     want = oracle.process_fast(query.cpu().numpy(), pts, edges[:2], radii[:2])
     assert_features_close(c.cpu().numpy()[:, :8], want, pts)
+
+
+# ---- edge cases --------------------------------------------------------------------------------------
+
+def test_empty_and_tiny_inputs():
+    search = synth.uniform_cloud(500, extent=2.0, seed=111)
+    out = multiscale.process_single_core(np.zeros((0, 3)), search, [0.2, 0.4], [0.6, 1.2])
+    assert out.shape == (0, 8)
+    out = multiscale.process_single_core(search, search, [], [])
+    assert out.shape == (500, 0)
+    two = np.array([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0]])
+    got = multiscale.process_single_core(two, two, [0.5], [2.0])
+    want = oracle.process_fast(two, two, [0.5], [2.0])
+    assert_features_close(got, want, two)
+    with pytest.raises(ValueError):
+        multiscale.process_single_core(two[:1], two[:1], [0.5], [2.0])     # geometry.py:34
+
+
+@pytest.mark.parametrize("ratio", [0.3, 0.49, 6.0, 8.4])
+def test_generic_kernel_radius_ratios(ratio):
+    # W = 1 (only the home voxel can qualify), W = 13 and W = 17: the generic kernel
+    pts = synth.uniform_cloud(3000, extent=2.0, seed=113)
+    e = 0.1
+    got = multiscale.process_single_core(pts, pts, [e], [ratio * e])
+    want = oracle.process_fast(pts, pts, [e], [ratio * e])
+    assert_features_close(got, want, pts)
+
+
+def test_duplicates_and_points_on_cell_boundaries():
+    rs = np.random.RandomState(115)
+    e = 0.25
+    base = rs.randint(0, 12, size=(4000, 3)).astype(np.float64) * e      # exactly on multiples of e
+    pts = np.concatenate((base, base[:1500], base[:700] + e / 2, rs.rand(500, 3) * 3.0), axis=0)
+    for r in (0.75, 0.5, 1.0):
+        got = multiscale.process_single_core(pts, pts, [e], [r])
+        want = oracle.process_fast(pts, pts, [e], [r])
+        assert_features_close(got, want, pts)
+    off, idx = multiscale.neighbor_lists(pts[:500], pts, e, 0.75)
+    voxels = oracle.Lattice(pts, e).unique_voxels(pts)
+    w_off, w_idx = oracle.neighbors_to_csr(oracle.ball_neighbors_kdtree(pts[:500], voxels, 0.75))
+    assert np.array_equal(off, w_off) and np.array_equal(idx, w_idx)
+
+
+def test_huge_coordinates_disable_window_pruning():
+    # 16 ulp of the largest coordinate exceeds 1e-4 cell: the kernel must test every candidate
+    pts = synth.uniform_cloud(4000, extent=1.0, seed=117) + np.array([3.0e9, -2.0e9, 1.0e9])
+    e, r = 0.05, 0.15
+    got = multiscale.process_single_core(pts, pts, [e], [r])
+    want = oracle.process_fast(pts, pts, [e], [r])
+    assert np.array_equal(got[:, 0], want[:, 0])
+    assert_features_close(got, want, pts)
+
+
+def test_wide_window_many_rows():
+    # W = 9 on a thin slab: long boxes, row cap and superblock table limits of the staging
+    rs = np.random.RandomState(119)
+    pts = np.concatenate((rs.rand(20000, 1) * 40.0, rs.rand(20000, 1) * 40.0, rs.rand(20000, 1) * 0.3),
+                         axis=1)
+    e = 0.1
+    got, info = multiscale.process_gpu(torch.from_numpy(pts).cuda(), torch.from_numpy(pts).cuda(),
+                                       [e], [4.0 * e], return_info=True)
+    want = oracle.process_fast(pts, pts, [e], [4.0 * e])
+    assert_features_close(got.cpu().numpy(), want, pts)
