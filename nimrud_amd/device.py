@@ -98,9 +98,14 @@ def row_stride(t):
     return int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
 
 
-def cloud_bounds(rt, t):
-    """(min xyz, max xyz) of the first three (or two) columns, computed on the device."""
+def cloud_bounds_device(rt, t):
+    """6 doubles {min xyz, max xyz} of the first three columns, left on the device."""
     out = torch.empty(6, dtype=torch.float64, device=rt.device)
     rt.check(rt.lib.nm_bounds(rt.ctx, ptr(t), t.shape[0], row_stride(t), ptr(out), rt.stream()))
-    mm = out.cpu().numpy()
+    return out
+
+
+def cloud_bounds(rt, t):
+    """(min xyz, max xyz) of the first three (or two) columns, computed on the device."""
+    mm = cloud_bounds_device(rt, t).cpu().numpy()
     return mm[:3].copy(), mm[3:].copy()

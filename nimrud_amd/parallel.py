@@ -48,8 +48,7 @@ class HipBackend(object):
         self.device = self.rt.device
 
     def bounds(self, cloud):
-        lo, hi = _device.cloud_bounds(self.rt, cloud)
-        return torch.from_numpy(np.concatenate((lo, hi))).to(self.device)
+        return _device.cloud_bounds_device(self.rt, cloud)
 
     def halo_count(self, cloud, boxes, skip):
         rt = self.rt
@@ -75,19 +74,10 @@ class HipBackend(object):
                                     _device.row_stride(cloud), _device.ptr(out), rt.stream()))
 
     def features(self, search, n_query, lo, hi, edge_lengths, radii, out, info):
-        """scale loop: queries are the first n_query rows of `search`."""
-        from nimrud_amd.utils import geometry
-        rt = self.rt
-        for s, (e, r) in enumerate(zip(edge_lengths, radii)):
-            vf = geometry.VoxelFilter.from_bounds(lo, hi, e, device=self.device)
-            lat = vf.nm_lattice
-            nbytes = rt.lib.nm_scale_workspace_bytes(n_query, search.shape[0], ctypes.byref(lat))
-            work = rt.workspace(nbytes)
-            view = out[:, 4 * s:4 * s + 4]
-            rt.check(rt.lib.nm_scale_features(
-                rt.ctx, _device.ptr(search), n_query, 3, _device.ptr(search), search.shape[0], 3,
-                ctypes.byref(lat), float(r), _device.ptr(view), int(view.stride(0)),
-                _device.ptr(info[s]), _device.ptr(work), work.numel(), rt.stream()))
+        """the scale ladder (one library call): queries are the first n_query rows of `search`."""
+        from nimrud_amd.minimal import multiscale
+        multiscale._ladder_into(self.rt, search[:n_query], search, True, lo, hi, edge_lengths, radii,
+                                out, info)
 
 
 class TilePlan(object):
@@ -127,7 +117,8 @@ class TilePlan(object):
 
 
 def exchange_halo(plan):
-    """steps 2-4: returns (global lo, global hi, received halo rows (H,3))."""
+    """steps 2-4: returns (global lo, global hi, received halo rows (H,3)).  one host synchronisation:
+    the split sizes of the all-to-all-v and the global extrema are read back together."""
     be, cloud, group = plan.backend, plan.cloud, plan.group
     dev = cloud.device
     local = be.bounds(cloud)                               # (6,) lo xyz, hi xyz on the device
@@ -148,9 +139,13 @@ def exchange_halo(plan):
     send_counts = be.halo_count(cloud, boxes, plan.rank).to(cdev)
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
-    send_list = [int(v) for v in send_counts.cpu()]
-    recv_list = [int(v) for v in recv_counts.cpu()]
-    offsets = torch.zeros(plan.world, dtype=torch.int64)
+    # the one read-back: counts (as doubles, exact below 2^53) next to the global extrema
+    host = torch.cat((send_counts.to(torch.float64), recv_counts.to(torch.float64), glo, ghi)).cpu()
+    w = plan.world
+    send_list = [int(v) for v in host[:w]]
+    recv_list = [int(v) for v in host[w:2 * w]]
+    glo_h, ghi_h = host[2 * w:2 * w + 3].numpy().copy(), host[2 * w + 3:].numpy().copy()
+    offsets = torch.zeros(w, dtype=torch.int64)
     offsets[1:] = torch.cumsum(torch.tensor(send_list[:-1], dtype=torch.int64), 0)
     packed = be.halo_pack(cloud, boxes, plan.rank, offsets.to(dev), sum(send_list)).to(cdev)
     recv = torch.empty((sum(recv_list), 3), dtype=torch.float64, device=cdev)
@@ -158,7 +153,7 @@ def exchange_halo(plan):
                            [3 * c for c in recv_list], [3 * c for c in send_list], group=group)
     recv = recv.to(dev)
     plan.halo_sent, plan.halo_received = sum(send_list), sum(recv_list)
-    return glo.cpu().numpy(), ghi.cpu().numpy(), recv
+    return glo_h, ghi_h, recv
 
 
 def process_tile(plan, out=None):
