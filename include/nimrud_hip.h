@@ -148,6 +148,16 @@ int nm_multiscale_features(nm_ctx* ctx,
                            double* d_feat, int64_t feat_stride, int64_t* d_info,
                            void* d_work, size_t work_bytes, void* stream);
 
+/* ---- k-nearest-voxel fallback (BASELINE config 4; no reference counterpart) -----------------------------
+ * build-defined extension: while k_min > 0, nm_scale_features / nm_multiscale_features re-evaluate every
+ * query whose radius neighborhood holds fewer than k_min voxels on the k_min nearest voxel centres within
+ * radius_factor * radius (fewer if there are not that many; ties broken by smaller voxel address).
+ * column 0 keeps the radius population; centroid distance and eigen-features come from the k-NN set.
+ * k_min <= 16.  the reference has nothing of the kind (its only kNN mention is a classifier with a
+ * missing import, prototypes/apc.py:1479); parity is pinned by the build's own oracle
+ * (oracle.one_scale_knn: cKDTree.query on the same voxel set).                                       */
+int nm_set_knn_fallback(nm_ctx* ctx, int k_min, double radius_factor);
+
 /* ---- neighbor lists (parity / inspection mode) -----------------------------------------------------
  * the neighbor_idx lists of multiscale.py:103 as CSR.  two calls: with d_nbr_index == NULL the
  * per-query counts are written to d_nbr_count (int32[n_query]); the caller turns them into offsets
@@ -185,6 +195,15 @@ int nm_halo_pack(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, co
                  double* d_out, void* stream);
 int nm_copy_xyz(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, double* d_out,
                 void* stream);
+
+/* ---- derived descriptors ------------------------------------------------
+ * linearity (l1-l2)/l1, planarity (l2-l3)/l1 and scatter l3/l1 per scale, from the normalised
+ * eigenvalues of a feature matrix produced by nm_(multi)scale_features (l3 = 1 - l1 - l2).  the
+ * reference's minimal path stops at (l1, l2) (features.py:57); its legacy generation carries full
+ * covariance / eigenvector variants (prototypes/mso.py:1315,1555).  d_out is (n, out_stride) with 3
+ * columns per scale; undefined rows give zeros.                                                    */
+int nm_descriptors(nm_ctx* ctx, const double* d_feat, int64_t n, int32_t n_scales, int64_t feat_stride,
+                   double* d_out, int64_t out_stride, void* stream);
 
 /* ---- classifier slot -------------------------------------------------------------------------------
  * nimrud/minimal/classification.py is a stub; the reference's classifier is sklearn's

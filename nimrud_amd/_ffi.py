@@ -48,6 +48,7 @@ SIGNATURES = {
     "nm_destroy": (None, [c_ptr]),
     "nm_last_error": (ctypes.c_char_p, [c_ptr]),
     "nm_abi_version": (ctypes.c_int, []),
+    "nm_set_knn_fallback": (ctypes.c_int, [c_ptr, ctypes.c_int, c_f64]),
     "nm_profile_begin": (ctypes.c_int, [c_ptr]),
     "nm_set_overlap": (ctypes.c_int, [c_ptr, ctypes.c_int]),
     "nm_profile_end": (ctypes.c_int, [c_ptr, ctypes.POINTER(c_f64 * 4), ctypes.POINTER(c_i64)]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "nm_halo_pack": (ctypes.c_int,
                      [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nm_copy_xyz": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "nm_descriptors": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i32, c_i64, c_ptr, c_i64, c_ptr]),
     "nm_forest_eval": (ctypes.c_int,
                        [c_ptr, ctypes.POINTER(NmForest), c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
 }

@@ -41,6 +41,16 @@ extern "C" int nm_set_overlap(nm_ctx* ctx, int enabled)
     return NM_OK;
 }
 
+extern "C" int nm_set_knn_fallback(nm_ctx* ctx, int k_min, double radius_factor)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (k_min < 0 || k_min > 16 || (k_min > 0 && !(radius_factor >= 1.0)))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_knn_fallback: k_min in [0,16], radius_factor >= 1");
+    ctx->knn_k = k_min;
+    if (k_min > 0) ctx->knn_radius_factor = radius_factor;
+    return NM_OK;
+}
+
 extern "C" int nm_profile_begin(nm_ctx* ctx)
 {
     if (!ctx) return NM_ERR_INVALID;
@@ -133,6 +143,50 @@ extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double
     k_forest_eval<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(*forest, d_feat, n,
                                                                           feat_stride, d_proba,
                                                                           d_label);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+
+// ---- derived descriptors --------------------------------------------------------------------------------
+// linearity (l1-l2)/l1, planarity (l2-l3)/l1, scatter l3/l1 from the normalised eigenvalues the feature
+// matrix already holds (l1, l2 in columns 4s+2, 4s+3; l3 = 1 - l1 - l2).  rows whose eigen-features are
+// undefined (zeros) give zeros.
+__global__ __launch_bounds__(256) void k_descriptors(const double* __restrict__ feat, int64_t n,
+                                                     int32_t n_scales, int64_t fstride,
+                                                     double* __restrict__ out, int64_t ostride)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * n_scales) return;
+    const int64_t row = t / n_scales;
+    const int32_t s = (int32_t)(t - row * n_scales);
+    const double l1 = feat[row * fstride + 4 * s + 2], l2 = feat[row * fstride + 4 * s + 3];
+    double lin = 0.0, pla = 0.0, sca = 0.0;
+    if (l1 > 0.0) {
+        double l3 = 1.0 - l1 - l2;
+        l3 = l3 < 0.0 ? 0.0 : l3;
+        const double inv = 1.0 / l1;
+        lin = (l1 - l2) * inv;
+        pla = (l2 - l3) * inv;
+        sca = l3 * inv;
+    }
+    double* o = out + row * ostride + 3 * s;
+    o[0] = lin;
+    o[1] = pla;
+    o[2] = sca;
+}
+
+extern "C" int nm_descriptors(nm_ctx* ctx, const double* d_feat, int64_t n, int32_t n_scales,
+                              int64_t feat_stride, double* d_out, int64_t out_stride, void* stream)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (n < 0 || n_scales < 0 || feat_stride < 4 * (int64_t)n_scales ||
+        out_stride < 3 * (int64_t)n_scales || (n > 0 && n_scales > 0 && (!d_feat || !d_out)))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_descriptors: bad arguments");
+    const int64_t total = n * n_scales;
+    if (total == 0) return NM_OK;
+    k_descriptors<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        d_feat, n, n_scales, feat_stride, d_out, out_stride);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }

@@ -23,6 +23,9 @@ struct nm_ctx {
     int ladder_waves = 5;        // fused-kernel workgroups per SIMD while a build runs beside it
     hipStream_t aux = nullptr;
     std::vector<hipEvent_t> sync_events;
+    // k-nearest-voxel fallback for sparse neighborhoods (nm_set_knn_fallback); 0 = off
+    int knn_k = 0;
+    double knn_radius_factor = 3.0;
 };
 
 // next profiling event recorded on `s`, or a no-op when profiling is off

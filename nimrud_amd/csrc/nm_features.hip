@@ -649,6 +649,143 @@ __global__ void k_publish_info(const uint32_t* counters, int64_t* info)
     }
 }
 
+// ---- k-nearest-voxel fallback -------------------------------------------------------------------------
+// queries whose radius neighborhood has fewer than k voxels are re-evaluated on their k nearest occupied
+// voxel centres within rk (rk2 = rk*rk).  one lane per query, Chebyshev shells around the home cell; a
+// shell s is final once the k-th best distance is below (s + 1/2) cells, because every cell not yet
+// visited lies at least that far away.  rare path: direct index lookups, exact fp64 distances in the
+// reference's operation order, ties broken by the smaller voxel address.
+constexpr int NM_KNN_MAX = 16;
+
+struct KnnArgs {
+    ScaleArgs S;
+    int32_t k;
+    double rk2;
+    int32_t max_shell;
+};
+
+__global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
+{
+    const ScaleArgs& A = K.S;
+    const LatticeDev& L = A.L;
+    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (slot >= A.n_slots) return;
+    const uint32_t qi = A.order[slot];
+    if (qi >= A.nq) return;
+    double* o = A.feat + (int64_t)qi * A.fstride;
+    if (o[0] >= (double)K.k) return;
+    const double* p = A.query + (A.direct ? slot : (int64_t)qi) * A.qstride;
+    const double qx = p[0], qy = p[1], qz = p[2];
+    const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
+    const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
+    const int32_t hz = nm_clamp_cell(nm_cell_f(qz, L.min_z, L.edge));
+
+    double bd[NM_KNN_MAX];
+    int64_t bc[NM_KNN_MAX];      // address-like code of the voxel: tie break and offsets
+#pragma unroll
+    for (int t = 0; t < NM_KNN_MAX; ++t) {
+        bd[t] = INFINITY;
+        bc[t] = INT64_MAX;
+    }
+    int32_t found = 0;
+    for (int32_t s = 0; s <= K.max_shell; ++s) {
+        for (int32_t dz = -s; dz <= s; ++dz) {
+            const int32_t gz = hz + dz;
+            if (gz < 0 || gz >= (1 << L.wz)) continue;
+            double d = qz - nm_centre(gz, L.min_z, L.edge, L.half_edge);
+            const double dz2 = d * d;
+            for (int32_t dy = -s; dy <= s; ++dy) {
+                const int32_t gy = hy + dy;
+                if (gy < 0 || gy >= (1 << L.wy)) continue;
+                d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
+                const double dy2 = d * d;
+                const bool face = (dz == -s || dz == s || dy == -s || dy == s);
+                const int32_t step = (face || s == 0) ? 1 : 2 * s;     // whole row, or its two ends
+                int32_t cached_sb = INT32_MIN;
+                uint32_t word = 0;
+                for (int32_t dx = -s; dx <= s; dx += step) {
+                    const int32_t gx = hx + dx;
+                    if (gx < 0 || gx >= (1 << L.wx)) continue;
+                    const int32_t sbx = gx >> NM_SBX_BITS;
+                    if (sbx != cached_sb) {
+                        cached_sb = sbx;
+                        const int32_t leaf = nm_hash_find(
+                            A.I, nm_sb_key((uint32_t)sbx, (uint32_t)(gy >> NM_SBY_BITS),
+                                           (uint32_t)(gz >> NM_SBZ_BITS), L));
+                        word = leaf >= 0
+                                   ? A.I.leaf[(size_t)leaf * NM_LEAF_WORDS + (gz & 7) * 8 + (gy & 7)]
+                                   : 0u;
+                    }
+                    if (!((word >> (gx & 31)) & 1u)) continue;
+                    d = qx - nm_centre(gx, L.min_x, L.edge, L.half_edge);
+                    double cd = (d * d + dy2) + dz2;
+                    if (!(cd <= K.rk2)) continue;
+                    // offsets from the home cell, biased, z high / x low: the same order as the
+                    // reference's voxel address, which is the tie break
+                    int64_t cc = ((int64_t)(dz + 1024) << 22) | ((int64_t)(dy + 1024) << 11) |
+                                 (int64_t)(dx + 1024);
+                    ++found;
+                    // insertion into the sorted top list (static indices: stays in registers)
+#pragma unroll
+                    for (int t = 0; t < NM_KNN_MAX; ++t) {
+                        const bool before = cd < bd[t] || (cd == bd[t] && cc < bc[t]);
+                        const double td = before ? bd[t] : cd;
+                        const int64_t tc = before ? bc[t] : cc;
+                        bd[t] = before ? cd : bd[t];
+                        bc[t] = before ? cc : bc[t];
+                        cd = td;
+                        cc = tc;
+                    }
+                }
+            }
+        }
+        // k-th best so far
+        double kth = INFINITY;
+#pragma unroll
+        for (int t = 0; t < NM_KNN_MAX; ++t)
+            if (t == K.k - 1) kth = bd[t];
+        const double reach = ((double)s + 0.5 - 1e-6) * L.edge;     // nothing unvisited is closer
+        if (kth <= reach * reach) break;
+        if (reach * reach > K.rk2) break;                            // nothing unvisited is in range
+    }
+    const int32_t use = found < K.k ? found : K.k;
+    double n = 0, sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+#pragma unroll
+    for (int t = 0; t < NM_KNN_MAX; ++t) {
+        if (t < use) {
+            const double ox = (double)((int32_t)(bc[t] & 0x7FF) - 1024);
+            const double oy = (double)((int32_t)((bc[t] >> 11) & 0x7FF) - 1024);
+            const double oz = (double)((int32_t)(bc[t] >> 22) - 1024);
+            n += 1.0;
+            sx += ox; sy += oy; sz += oz;
+            sxx += ox * ox; sxy += ox * oy; sxz += ox * oz;
+            syy += oy * oy; syz += oy * oz; szz += oz * oz;
+        }
+    }
+    double out[4];
+    const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
+    const double uy = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
+    const double uz = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
+    nm_features_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, ux, uy, uz, 0.0, L.edge, out);
+    o[1] = out[1];
+    o[2] = out[2];
+    o[3] = out[3];
+}
+
+static void launch_knn_fallback(nm_ctx* ctx, const ScaleArgs& A, double radius, hipStream_t s)
+{
+    if (ctx->knn_k <= 0 || A.nq <= 0) return;
+    KnnArgs K;
+    K.S = A;
+    K.k = ctx->knn_k;
+    const double rk = radius * ctx->knn_radius_factor;
+    K.rk2 = rk * rk;
+    double shells = ceil(rk / A.L.edge + 0.5);
+    if (shells > 1000.0) shells = 1000.0;
+    K.max_shell = (int32_t)shells;
+    k_knn_fallback<<<(int)((A.n_slots + 63) / 64), 64, 0, s>>>(K);
+}
+
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // candidates per axis: all integer offsets d with |d + 1/2 - f| <= r/e for some f in [0,1), with a
@@ -830,6 +967,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.fstride = feat_stride;
         A.stats = I.counters + 8;
         launch_scale_kernel(A, lat, radius, W, s, ctx->num_cus, 6);
+        launch_knn_fallback(ctx, A, radius, s);
     }
     nm_profile_mark(ctx, s);
     NM_HIP(ctx, hipGetLastError());
@@ -1030,6 +1168,7 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
             A.fstride = feat_stride;
             A.stats = I.counters + 8;
             launch_scale_kernel(A, &lats[i], radii[i], W, s, ctx->num_cus, overlap ? ctx->ladder_waves : 6);
+            launch_knn_fallback(ctx, A, radii[i], s);
         }
         nm_profile_mark(ctx, s);
         NM_HIP(ctx, hipGetLastError());

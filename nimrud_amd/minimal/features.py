@@ -78,3 +78,19 @@ def pca(neighborhood_points, strict=False):
             raise FloatingPointError("covariance undefined for fewer than 2 points")
         return np.zeros(2)
     return _single(None, neighborhood_points)[2:4].copy()
+
+
+def descriptors(feature_matrix):
+    """linearity, planarity, scatter per scale from a (N, 4*S) feature matrix of the multiscale pipeline:
+    (l1-l2)/l1, (l2-l3)/l1, l3/l1 with l3 = 1 - l1 - l2.  returns (N, 3*S); undefined rows are zeros.
+    an addition to the reference, whose minimal path stops at (l1, l2) (features.py:57)."""
+    as_torch = isinstance(feature_matrix, torch.Tensor)
+    rt, feat = _device.as_cloud(feature_matrix)
+    n, cols = feat.shape
+    if cols % 4:
+        raise ValueError("feature matrix must have 4 columns per scale")
+    n_scales = cols // 4
+    out = torch.empty((n, 3 * n_scales), dtype=torch.float64, device=rt.device)
+    rt.check(rt.lib.nm_descriptors(rt.ctx, _device.ptr(feat), n, n_scales, _device.row_stride(feat),
+                                   _device.ptr(out), 3 * n_scales, rt.stream()))
+    return out if as_torch else out.cpu().numpy()

@@ -86,12 +86,15 @@ def _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, in
 
 
 def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, strict=False,
-                return_info=False, out=None, per_scale=False):
+                return_info=False, out=None, per_scale=False, knn_min=0, knn_radius_factor=3.0):
     """process_single_core for clouds resident in HBM: torch GPU tensors in, (Nq, 4*S) fp64 GPU tensor
     out.  nothing crosses PCIe except six doubles (the search cloud's extrema) and, when strict or
     return_info, 4 counters per scale.
     the ladder normally runs as ONE library call that sorts the cloud once for all scales;
-    verbose=True or per_scale=True runs one self-contained call per scale instead (same numbers)."""
+    verbose=True or per_scale=True runs one self-contained call per scale instead (same numbers).
+    knn_min > 0 switches on the k-nearest-voxel fallback (an extension the reference does not have,
+    BASELINE config 4): neighborhoods with fewer than knn_min voxels take their centroid and eigen
+    features from the knn_min nearest voxels within knn_radius_factor * radius."""
     assert len(edge_lengths) == len(radii), \
         "edge_lengths and radii should be equal-length sequences."
     shared = query_cloud is search_cloud
@@ -111,6 +114,7 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
 
     outer_start = time.perf_counter()
     lo, hi = _device.cloud_bounds(rt, search)
+    rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
     if not (verbose or per_scale):
         _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info)
         edge_lengths_loop = []
@@ -153,15 +157,18 @@ def one_scale_gpu(query_cloud, search_cloud, edge_length, radius, verbose=False,
                        strict=strict)
 
 
-def process_single_core(query_cloud, search_cloud, edge_lengths, radii, verbose=False, strict=False):
+def process_single_core(query_cloud, search_cloud, edge_lengths, radii, verbose=False, strict=False,
+                        knn_min=0, knn_radius_factor=3.0):
     """compute features at multiple scales.  returns an array of feature vectors aligned with the
-    query cloud: numpy (Nq, 4*S) fp64, scale blocks in caller order (multiscale.py:27-67)."""
+    query cloud: numpy (Nq, 4*S) fp64, scale blocks in caller order (multiscale.py:27-67).
+    knn_min / knn_radius_factor: see process_gpu (extension, off by default)."""
     assert len(edge_lengths) == len(radii), \
         "edge_lengths and radii should be equal-length sequences."
     shared = query_cloud is search_cloud
     rt, search = _device.as_cloud(search_cloud)
     query = search if shared else _device.as_cloud(query_cloud, rt.device)[1]
-    result = process_gpu(query, search, edge_lengths, radii, verbose=verbose, strict=strict)
+    result = process_gpu(query, search, edge_lengths, radii, verbose=verbose, strict=strict,
+                         knn_min=knn_min, knn_radius_factor=knn_radius_factor)
     return result.cpu().numpy()
 
 

@@ -460,3 +460,48 @@ def test_wide_window_many_rows():
                                        [e], [4.0 * e], return_info=True)
     want = oracle.process_fast(pts, pts, [e], [4.0 * e])
     assert_features_close(got.cpu().numpy(), want, pts)
+
+
+# ---- k-nearest-voxel fallback (config 4; build-defined, pinned by the build's own oracle) --------------
+
+@pytest.mark.parametrize("per_scale", [False, True])
+def test_knn_fallback_against_oracle(per_scale):
+    # a dense core plus a sparse halo of stragglers whose radius neighborhoods are nearly empty
+    rs = np.random.RandomState(131)
+    core, _ = synth.scene_cloud(20000, extent=6.0, n_poles=4, n_spheres=2, seed=132)
+    sparse = rs.rand(1500, 3) * np.array([12.0, 12.0, 4.0]) - np.array([3.0, 3.0, 0.5])
+    pts = np.concatenate((core, sparse), axis=0)
+    e, r, k = 0.1, 0.3, 8
+    dev = torch.from_numpy(pts).cuda()
+    got = multiscale.process_gpu(dev, dev, [e], [r], knn_min=k, knn_radius_factor=4.0,
+                                 per_scale=per_scale).cpu().numpy()
+    want = oracle.one_scale_knn(pts, pts, e, r, k, radius_factor=4.0)
+    plain = oracle.one_scale_fast(pts, pts, e, r)
+    touched = plain[:, 0] < k
+    assert touched.sum() > 500 and (~touched).sum() > 5000
+    assert np.array_equal(got[:, 0], want[:, 0])                 # population column is untouched
+    assert_features_close(got, want, pts)
+    assert np.abs(want[touched] - plain[touched]).max() > 1e-3   # the fallback really changed rows
+    # and switching it off again restores the plain result
+    off = multiscale.process_gpu(dev, dev, [e], [r]).cpu().numpy()
+    assert_features_close(off, plain, pts)
+
+
+def test_descriptors():
+    pts, _ = synth.scene_cloud(20000, extent=8.0, n_poles=5, n_spheres=2, seed=141)
+    feats = multiscale.process_single_core(pts, pts, [0.1, 0.2], [0.3, 0.6])
+    feats[:5, 2:4] = 0.0                                           # undefined rows
+    got = features.descriptors(feats)
+    assert got.shape == (len(pts), 6)
+    for s in range(2):
+        l1, l2 = feats[:, 4 * s + 2], feats[:, 4 * s + 3]
+        l3 = np.maximum(1.0 - l1 - l2, 0.0)
+        ok = l1 > 0
+        want = np.zeros((len(pts), 3))
+        want[ok] = np.stack(((l1 - l2)[ok] / l1[ok], (l2 - l3)[ok] / l1[ok], l3[ok] / l1[ok]), axis=1)
+        assert np.abs(got[:, 3 * s:3 * s + 3] - want).max() < 1e-14
+    assert np.all(got[:5, :3] == 0.0)
+    # ground points are planar, pole points linear
+    _, labels = synth.scene_cloud(20000, extent=8.0, n_poles=5, n_spheres=2, seed=141)
+    d = features.descriptors(multiscale.process_single_core(pts, pts, [0.2], [0.6]))
+    assert np.median(d[labels == 0, 1]) > 0.6 and np.median(d[labels == 1, 0]) > 0.5

@@ -159,3 +159,25 @@ def test_oracle_forest_matches_reference(golden):
     proba = oracle.forest_predict_proba(model, g["x"])
     assert np.abs(proba - g["proba"]).max() <= 1e-15
     assert np.array_equal(oracle.forest_predict(model, g["x"]), g["label"])
+
+
+def test_oracle_knn_fallback_definition():
+    # build-defined extension (config 4): rows with population >= k are untouched; the others use the
+    # k nearest voxel centres within the radius factor (checked against a brute-force selection)
+    from nimrud_amd import synth
+    rs = np.random.RandomState(3)
+    pts = np.concatenate((synth.uniform_cloud(1500, extent=1.5, seed=4), rs.rand(200, 3) * 6.0 - 2.0))
+    e, r, k, factor = 0.1, 0.3, 6, 4.0
+    plain = oracle.one_scale_fast(pts, pts, e, r)
+    knn = oracle.one_scale_knn(pts, pts, e, r, k, radius_factor=factor)
+    dense = plain[:, 0] >= k
+    assert dense.sum() > 100 and (~dense).sum() > 50
+    assert np.array_equal(knn[dense], plain[dense])
+    assert np.array_equal(knn[:, 0], plain[:, 0])
+    voxels = oracle.Lattice(pts, e).unique_voxels(pts)
+    for row in np.nonzero(~dense)[0][:40]:
+        d = np.linalg.norm(voxels - pts[row], axis=1)
+        pick = np.argsort(d, kind="stable")[:k]
+        nb = voxels[pick[d[pick] <= r * factor]]
+        assert abs(knn[row, 1] - oracle.centroid(pts[row], nb)) < 1e-12
+        assert np.abs(knn[row, 2:] - oracle.pca(nb)).max() < 1e-12
