@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, "libnimrud_hip.so")
+# NIMRUD_HIP_LIBRARY selects another build of the same ABI (diagnostic builds); default: in-tree
+LIBRARY_PATH = os.environ.get("NIMRUD_HIP_LIBRARY") or os.path.join(_HERE, "libnimrud_hip.so")
 
 NM_OK = 0
 NM_ERR_INVALID = -1
