@@ -587,6 +587,85 @@ __global__ __launch_bounds__(256) void k_cell_keys_only(const double* __restrict
     key[i] = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
 }
 
+__device__ __forceinline__ uint64_t nm_point_key(const double* __restrict__ p, const LatticeDev& L)
+{
+    int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
+    int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
+    int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
+    cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
+    cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
+    cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
+    return nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
+}
+
+// k_cell_keys_only + k_index_insert in one pass over the coordinate stream: the keys are computed,
+// stored for k_index_bits_any, and the run heads go to the hash table.
+__global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restrict__ xyz, int64_t n,
+                                                           LatticeDev L, uint64_t* __restrict__ key,
+                                                           IndexDev I)
+{
+    __shared__ uint32_t won_slot[INDEX_CHUNK];
+    __shared__ uint32_t won_count;
+    __shared__ uint32_t leaf_base;
+    if (threadIdx.x == 0) won_count = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
+    // superblock of the key just before this wave's first one
+    uint64_t carry = ~0ull;
+    if (wave_lo > 0 && wave_lo <= n) carry = nm_point_key(xyz + (wave_lo - 1) * 3, L) >> NM_LOCAL_BITS;
+    for (int it = 0; it < INDEX_ITERS; ++it) {
+        const int64_t i = wave_lo + it * 64 + lane;
+        if (wave_lo + it * 64 >= n) break;
+        const bool valid = i < n;
+        uint64_t k = 0ull;
+        if (valid) {
+            k = nm_point_key(xyz + i * 3, L);
+            key[i] = k;
+        }
+        const uint64_t sb = k >> NM_LOCAL_BITS;
+        uint64_t prev = __shfl_up(sb, 1);
+        if (lane == 0) prev = carry;
+        carry = __shfl(sb, 63);
+        if (valid && sb != prev) {
+            uint32_t slot = nm_hash64(sb) & I.hash_mask;
+            for (;;) {
+                const uint64_t peek = I.hash_key[slot];
+                if (peek == sb) break;
+                if (peek != NM_HASH_EMPTY) {
+                    slot = (slot + 1) & I.hash_mask;
+                    continue;
+                }
+                const unsigned long long seen =
+                    atomicCAS((unsigned long long*)&I.hash_key[slot],
+                              (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
+                if (seen == NM_HASH_EMPTY) {
+                    won_slot[atomicAdd(&won_count, 1u)] = slot;
+                    break;
+                }
+                if (seen == sb) break;
+                slot = (slot + 1) & I.hash_mask;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = won_count;
+    if (total == 0) return;
+    if (threadIdx.x == 0) leaf_base = atomicAdd(&I.counters[0], total);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
+        const uint32_t idx = leaf_base + t;
+        if (idx >= I.leaf_capacity) {
+            I.counters[2] = 1u;
+            continue;
+        }
+        uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
+#pragma unroll
+        for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
+        I.hash_val[won_slot[t]] = idx;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_index_insert(const uint64_t* __restrict__ key, int64_t n,
                                                       IndexDev I)
 {
@@ -764,10 +843,9 @@ int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const L
     I.leaf_capacity = lay.leaf_capacity;
     NM_HIP(ctx, hipMemsetAsync(I.hash_key, 0xFF, (size_t)lay.hash_capacity * 8, s));
     NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
-    k_cell_keys_only<<<(int)((n + 255) / 256), 256, 0, s>>>(sorted_xyz, n, 3, L, key_buf);
-    nm_profile_mark(ctx, s);      // end of the "keys" stage, start of the "index" stage
+    nm_profile_mark(ctx, s);      // end of the "keys" stage (order build), start of the "index" stage
     const int blocks = (int)((n + INDEX_CHUNK - 1) / INDEX_CHUNK);
-    k_index_insert<<<blocks, 256, 0, s>>>(key_buf, n, I);
+    k_index_keys_insert<<<blocks, 256, 0, s>>>(sorted_xyz, n, L, key_buf, I);
     k_index_bits_any<<<blocks, 256, 0, s>>>(key_buf, n, I);
     NM_HIP(ctx, hipGetLastError());
     *out = I;
