@@ -118,8 +118,11 @@ def main():
     n_points = args.points or cfg["n"]
     points, _, edges, radii = synth.make_config(args.workload, n=n_points, seed_offset=rank)
     if world > 1:
-        extent = points[:, 0].max() - points[:, 0].min()
-        points[:, 0] += rank * float(np.ceil(extent))
+        # tiles abut along x (ground planes tile seamlessly; spheres and poles near a seam reach into
+        # the neighbour), so every seam carries a real halo of width max(radius + 0.87 edge)
+        extent = cfg.get("extent", 0.0) * (np.sqrt(n_points / cfg["n"]) if cfg["kind"] == "scene"
+                                           else (n_points / cfg["n"]) ** (1.0 / 3.0))
+        points[:, 0] += rank * float(extent)
     cloud = torch.from_numpy(points).to(dev)
     n_scales = len(edges)
     rt = nm_device.get_runtime(dev)

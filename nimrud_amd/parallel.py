@@ -106,6 +106,18 @@ class TilePlan(object):
         self._search_points = cloud.shape[0]
         self.halo_sent = 0
         self.halo_received = 0
+        # the tile's coordinates live at the front of a (N + slack, 3) buffer; halo rows are received
+        # straight behind them, so a step never copies the tile
+        self._buffer = None
+        self._ensure_buffer(max(1024, cloud.shape[0] // 8))
+
+    def _ensure_buffer(self, halo_rows):
+        n = self.cloud.shape[0]
+        if self._buffer is not None and self._buffer.shape[0] >= n + halo_rows:
+            return
+        self._buffer = torch.empty((n + halo_rows + halo_rows // 4, 3), dtype=torch.float64,
+                                   device=self.cloud.device)
+        self.backend.copy_xyz(self.cloud, self._buffer[:n])
 
     def last_info(self):
         from nimrud_amd.minimal.multiscale import ScaleInfo
@@ -117,14 +129,15 @@ class TilePlan(object):
 
 
 def exchange_halo(plan):
-    """steps 2-4: returns (global lo, global hi, received halo rows (H,3)).  one host synchronisation:
-    the split sizes of the all-to-all-v and the global extrema are read back together."""
+    """steps 2-4: returns (global lo, global hi, H); the H received halo rows sit in
+    plan._buffer[N:N+H].  one host synchronisation: the split sizes of the all-to-all-v and the global
+    extrema are read back together."""
     be, cloud, group = plan.backend, plan.cloud, plan.group
     dev = cloud.device
     local = be.bounds(cloud)                               # (6,) lo xyz, hi xyz on the device
     if plan.world == 1:
         mm = local.cpu().numpy()
-        return mm[:3], mm[3:], torch.empty((0, 3), dtype=torch.float64, device=dev)
+        return mm[:3], mm[3:], 0
     cdev = torch.device("cpu") if plan.stage_on_host else dev    # where the collectives run
     local_c = local.to(cdev)
     glo = local_c[:3].clone()
@@ -148,12 +161,18 @@ def exchange_halo(plan):
     offsets = torch.zeros(w, dtype=torch.int64)
     offsets[1:] = torch.cumsum(torch.tensor(send_list[:-1], dtype=torch.int64), 0)
     packed = be.halo_pack(cloud, boxes, plan.rank, offsets.to(dev), sum(send_list)).to(cdev)
-    recv = torch.empty((sum(recv_list), 3), dtype=torch.float64, device=cdev)
+    n, h = cloud.shape[0], sum(recv_list)
+    plan._ensure_buffer(h)
+    if plan.stage_on_host:
+        recv = torch.empty((h, 3), dtype=torch.float64, device=cdev)
+    else:
+        recv = plan._buffer[n:n + h]                       # RCCL writes the halo behind the tile
     dist.all_to_all_single(recv.reshape(-1), packed.reshape(-1),
                            [3 * c for c in recv_list], [3 * c for c in send_list], group=group)
-    recv = recv.to(dev)
-    plan.halo_sent, plan.halo_received = sum(send_list), sum(recv_list)
-    return glo_h, ghi_h, recv
+    if plan.stage_on_host:
+        plan._buffer[n:n + h] = recv.to(dev)
+    plan.halo_sent, plan.halo_received = sum(send_list), h
+    return glo_h, ghi_h, h
 
 
 def process_tile(plan, out=None):
@@ -162,11 +181,8 @@ def process_tile(plan, out=None):
     be, cloud = plan.backend, plan.cloud
     n = cloud.shape[0]
     n_scales = len(plan.edge_lengths)
-    lo, hi, halo = exchange_halo(plan)
-    search = torch.empty((n + halo.shape[0], 3), dtype=torch.float64, device=cloud.device)
-    be.copy_xyz(cloud, search[:n])
-    if halo.shape[0]:
-        search[n:] = halo
+    lo, hi, n_halo = exchange_halo(plan)
+    search = plan._buffer[:n + n_halo]
     plan._search_points = search.shape[0]
     if out is None:
         out = torch.empty((n, 4 * n_scales), dtype=torch.float64, device=cloud.device)
