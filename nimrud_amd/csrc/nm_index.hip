@@ -765,10 +765,10 @@ __global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restri
                 fresh = (uint32_t)__popc(bits & ~old);  // voxels nobody had set before
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) fresh += __shfl_xor(fresh, off);
-        cells += fresh;
+        cells += fresh;      // per lane; summed over the wave once, after the loop
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cells += __shfl_xor(cells, off);
     if (lane == 0) wcells[w] = cells;
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -505,3 +505,30 @@ def test_descriptors():
     _, labels = synth.scene_cloud(20000, extent=8.0, n_poles=5, n_spheres=2, seed=141)
     d = features.descriptors(multiscale.process_single_core(pts, pts, [0.2], [0.6]))
     assert np.median(d[labels == 0, 1]) > 0.6 and np.median(d[labels == 1, 0]) > 0.5
+
+
+def test_config3_full_size_properties():
+    # config 3 (the benchmark workload): 10M points x 5 scales.  at this size: range invariants on every
+    # row, voxel counts against numpy.unique on the host, and an oracle comparison on a spatial crop
+    # (the oracle gets the crop plus its halo and the GLOBAL lattice extrema).
+    pts, _, edges, radii = synth.make_config("c3_scene_10m")
+    dev = torch.from_numpy(pts).cuda()
+    full, info = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
+    f = full.cpu().numpy()
+    for s, e in enumerate(edges):
+        n, l1, l2 = f[:, 4 * s], f[:, 4 * s + 2], f[:, 4 * s + 3]
+        assert n.min() >= 1 and n.max() <= 123          # lattice points in a ball of radius 3
+        ok = n >= 2
+        assert np.all(l1[ok] >= 1.0 / 3.0 - 1e-12) and np.all(l1[ok] + l2[ok] <= 1.0 + 1e-12)
+        assert np.all(l2[ok] <= l1[ok] + 1e-12) and np.all(l2[ok] >= -1e-12)
+        assert np.all(f[:, 4 * s + 1] <= 3.0 * e + e)   # centroid lies within the ball (plus slack)
+        lat = oracle.Lattice(pts, e)
+        assert info[s].voxels == len(np.unique(lat.coordinate_to_address(pts)))
+    lo, hi = pts.min(0), pts.max(0)
+    centre = np.array([95.0, 95.0, 1.0])
+    inner = np.all(np.abs(pts[:, :2] - centre[:2]) <= 3.0, axis=1)
+    outer = np.all(np.abs(pts[:, :2] - centre[:2]) <= 3.0 + 3.2, axis=1)
+    rows = np.nonzero(inner)[0]
+    assert len(rows) > 5000
+    want = oracle.process_fast(pts[rows], pts[outer], edges, radii, bounds=(lo, hi))
+    assert_features_close(f[rows], want, pts)
