@@ -224,6 +224,16 @@ typedef struct nm_forest {
     int32_t n_trees;
     int32_t n_classes;
     int32_t n_features;
+    /* optional fast layout (both or neither): nodes renumbered so that the right child of node i is
+     * left(i) + 1, one 16-byte record per node {double threshold; int32 left; int32 feature}; a leaf has
+     * left = -1 and feature = its row in d_leaf_value (n_leaves x n_classes, rows sum to 1).
+     * d_packed_roots holds the root record of each tree.  with these set (and n_features <= 40) one
+     * record load replaces four array loads per node visit.                                         */
+    const void*    d_packed;
+    const double*  d_leaf_value;
+    const int32_t* d_packed_roots;
+    int32_t n_leaves;
+    int32_t reserved;
 } nm_forest;
 
 int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, int64_t n,

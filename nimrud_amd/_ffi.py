@@ -19,7 +19,7 @@ NM_ERR_WORKSPACE = -3
 NM_ERR_HIP = -4
 NM_ERR_RADIUS = -5
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_i64 = ctypes.c_int64
 c_i32 = ctypes.c_int32
@@ -38,7 +38,9 @@ class NmForest(ctypes.Structure):
     """struct nm_forest"""
     _fields_ = [("d_left", c_ptr), ("d_right", c_ptr), ("d_feature", c_ptr), ("d_threshold", c_ptr),
                 ("d_value", c_ptr), ("d_roots", c_ptr), ("n_nodes", c_i32), ("n_trees", c_i32),
-                ("n_classes", c_i32), ("n_features", c_i32)]
+                ("n_classes", c_i32), ("n_features", c_i32), ("d_packed", c_ptr),
+                ("d_leaf_value", c_ptr), ("d_packed_roots", c_ptr), ("n_leaves", c_i32),
+                ("reserved", c_i32)]
 
 
 _LATP = ctypes.POINTER(NmLattice)

@@ -5,7 +5,7 @@
 
 #include "nm_common.h"
 
-extern "C" int nm_abi_version(void) { return 1; }
+extern "C" int nm_abi_version(void) { return 2; }
 
 extern "C" int nm_create(nm_ctx** out, int device)
 {
@@ -129,20 +129,89 @@ __global__ __launch_bounds__(256) void k_forest_eval(nm_forest F, const double* 
     if (label) label[i] = best;
 }
 
+// packed-node evaluator: the block's 256 feature rows are staged in LDS as fp32 (sklearn casts X to
+// float32 anyway), transposed so that lane t reads bank t % 32 whatever feature it needs; a node visit
+// is one 16-byte record load and one LDS read.
+constexpr int NM_FOREST_MAX_FEATURES = 40;
+
+struct PackedNode {
+    double threshold;
+    int32_t left;
+    int32_t feature;
+};
+
+__global__ __launch_bounds__(256) void k_forest_eval_packed(nm_forest F, const double* __restrict__ feat,
+                                                            int64_t n, int64_t fstride,
+                                                            double* __restrict__ proba,
+                                                            int32_t* __restrict__ label)
+{
+    __shared__ float xs[NM_FOREST_MAX_FEATURES * 256];
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int nf = F.n_features;
+    const int rows_here = (int)((n - row0) < 256 ? (n - row0) : 256);
+    // rows are fstride apart; consecutive threads read consecutive columns of one row
+    for (int r = threadIdx.x / 32; r < rows_here; r += 8) {
+        const double* src = feat + (row0 + r) * fstride;
+        for (int f = threadIdx.x % 32; f < nf; f += 32) xs[f * 256 + r] = (float)src[f];
+    }
+    __syncthreads();
+    const int64_t i = row0 + threadIdx.x;
+    if (i >= n) return;
+    const PackedNode* nodes = (const PackedNode*)F.d_packed;
+    double acc[NM_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < NM_MAX_CLASSES; ++c) acc[c] = 0.0;
+    for (int t = 0; t < F.n_trees; ++t) {
+        int32_t node = F.d_packed_roots[t];
+        PackedNode rec = nodes[node];
+        while (rec.left >= 0) {
+            const double v = (double)xs[rec.feature * 256 + threadIdx.x];
+            node = rec.left + (v <= rec.threshold ? 0 : 1);
+            rec = nodes[node];
+        }
+        const double* val = F.d_leaf_value + (int64_t)rec.feature * F.n_classes;
+#pragma unroll
+        for (int c = 0; c < NM_MAX_CLASSES; ++c)
+            if (c < F.n_classes) acc[c] += val[c];
+    }
+    int best = 0;
+    double bestv = -1.0;
+#pragma unroll
+    for (int c = 0; c < NM_MAX_CLASSES; ++c) {
+        if (c < F.n_classes) {
+            const double pr = acc[c] / (double)F.n_trees;
+            if (proba) proba[i * F.n_classes + c] = pr;
+            if (pr > bestv) {
+                bestv = pr;
+                best = c;
+            }
+        }
+    }
+    if (label) label[i] = best;
+}
+
 extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, int64_t n,
                               int64_t feat_stride, double* d_proba, int32_t* d_label, void* stream)
 {
     if (!ctx) return NM_ERR_INVALID;
     if (!forest || n < 0 || (n > 0 && !d_feat) || (!d_proba && !d_label))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: bad arguments");
+    if (!forest->d_packed && (!forest->d_left || !forest->d_right || !forest->d_feature ||
+                              !forest->d_threshold || !forest->d_value || !forest->d_roots))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: node arrays missing");
     if (forest->n_classes < 1 || forest->n_classes > NM_MAX_CLASSES)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: n_classes must be in [1,%d]", NM_MAX_CLASSES);
     if (forest->n_trees < 1 || forest->n_features < 1 || feat_stride < forest->n_features)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: bad forest shape");
     if (n == 0) return NM_OK;
-    k_forest_eval<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(*forest, d_feat, n,
-                                                                          feat_stride, d_proba,
-                                                                          d_label);
+    const bool packed = forest->d_packed && forest->d_leaf_value && forest->d_packed_roots &&
+                        forest->n_features <= NM_FOREST_MAX_FEATURES;
+    if (packed)
+        k_forest_eval_packed<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+            *forest, d_feat, n, feat_stride, d_proba, d_label);
+    else
+        k_forest_eval<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+            *forest, d_feat, n, feat_stride, d_proba, d_label);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }

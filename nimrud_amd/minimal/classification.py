@@ -45,12 +45,49 @@ class ForestModel(object):
             int(np.asarray(feature).max()) + 1
         if self.value.ndim != 2 or self.value.shape[0] != self.left.shape[0]:
             raise ValueError("value must be (nodes, classes)")
+        packed, leaf_value, packed_roots = self.pack_nodes(
+            np.asarray(left, dtype=np.int32), np.asarray(right, dtype=np.int32),
+            np.asarray(feature, dtype=np.int32), np.asarray(threshold, dtype=np.float64),
+            np.ascontiguousarray(value, dtype=np.float64), np.asarray(roots, dtype=np.int32))
+        self.packed = torch.from_numpy(packed.view(np.uint8)).to(dev)
+        self.leaf_value = torch.from_numpy(leaf_value).to(dev)
+        self.packed_roots = torch.from_numpy(packed_roots).to(dev)
         self._c = _ffi.NmForest(
             d_left=self.left.data_ptr(), d_right=self.right.data_ptr(),
             d_feature=self.feature.data_ptr(), d_threshold=self.threshold.data_ptr(),
             d_value=self.value.data_ptr(), d_roots=self.roots.data_ptr(),
             n_nodes=self.left.shape[0], n_trees=self.roots.shape[0],
-            n_classes=self.value.shape[1], n_features=self.n_features)
+            n_classes=self.value.shape[1], n_features=self.n_features,
+            d_packed=self.packed.data_ptr(), d_leaf_value=self.leaf_value.data_ptr(),
+            d_packed_roots=self.packed_roots.data_ptr(), n_leaves=self.leaf_value.shape[0],
+            reserved=0)
+
+    @staticmethod
+    def pack_nodes(left, right, feature, threshold, value, roots):
+        """model preprocessing on the host (once per model, not on the data path): renumber the nodes
+        breadth-first so that siblings are adjacent (right = left + 1) and emit one 16-byte record per
+        node {f64 threshold, i32 left, i32 feature}; leaves get left = -1 and feature = row of their
+        class distribution in the returned leaf table."""
+        rec = np.zeros(len(left), dtype=np.dtype([("threshold", "<f8"), ("left", "<i4"),
+                                                  ("feature", "<i4")]))
+        leaf_rows = []
+        new_roots = np.zeros(len(roots), dtype=np.int32)
+        nxt = 0
+        for t, root in enumerate(roots):
+            new_roots[t] = nxt
+            queue = [(int(root), nxt)]
+            nxt += 1
+            while queue:
+                old, new = queue.pop(0)
+                if left[old] < 0:
+                    rec[new] = (0.0, -1, len(leaf_rows))
+                    leaf_rows.append(value[old])
+                else:
+                    rec[new] = (threshold[old], nxt, feature[old])
+                    queue.append((int(left[old]), nxt))
+                    queue.append((int(right[old]), nxt + 1))
+                    nxt += 2
+        return rec, np.ascontiguousarray(np.stack(leaf_rows)), new_roots
 
     @staticmethod
     def flatten_sklearn(clf):

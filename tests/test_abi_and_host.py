@@ -45,7 +45,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_ffi.NmLattice) == 56
     assert _ffi.NmLattice.edge.offset == 24 and _ffi.NmLattice.widths.offset == 32
     assert _ffi.NmLattice.shifts.offset == 44
-    assert ctypes.sizeof(_ffi.NmForest) == 6 * 8 + 4 * 4
+    assert ctypes.sizeof(_ffi.NmForest) == 9 * 8 + 6 * 4
 
 
 def test_workspace_queries_need_no_gpu():
