@@ -59,6 +59,40 @@ def scene_cloud(n, extent=60.0, n_poles=200, n_spheres=40, seed=1, offset=(0.0, 
     return _round32(points), labels[order]
 
 
+def lidar_cloud(n, seed=3, r_min=1.0, r_max=150.0, n_boxes=500):
+    """config 4: terrestrial-LiDAR-style cloud with power-law density.  a scanner stands 1.8 m above a
+    ground plane at the origin; ground returns have azimuth uniform and range R with pdf ~ R^-2 on
+    [r_min, r_max] (so areal density falls off as R^-3); 40 % of the returns lie on the vertical faces of
+    `n_boxes` box facades, each box weighted by its inverse squared distance.  labels: 0 ground, 1 facade."""
+    rs = np.random.RandomState(seed)
+    n_ground = int(round(0.6 * n))
+    n_facade = n - n_ground
+    u = rs.rand(n_ground)
+    rng = 1.0 / (1.0 / r_min - u * (1.0 / r_min - 1.0 / r_max))
+    az = rs.rand(n_ground) * 2 * np.pi
+    ground = np.stack((rng * np.cos(az), rng * np.sin(az), rs.randn(n_ground) * 0.01), axis=1)
+
+    baz = rs.rand(n_boxes) * 2 * np.pi
+    bdist = r_min + 4.0 + rs.rand(n_boxes) ** 0.5 * (r_max - r_min - 4.0)
+    centre = np.stack((bdist * np.cos(baz), bdist * np.sin(baz)), axis=1)
+    size = 4.0 + rs.rand(n_boxes, 2) * 12.0
+    height = 3.0 + rs.rand(n_boxes) * 12.0
+    weight = 1.0 / bdist ** 2
+    which = rs.choice(n_boxes, size=n_facade, p=weight / weight.sum())
+    face = rs.randint(0, 4, n_facade)
+    t = rs.rand(n_facade) - 0.5
+    sx, sy = size[which, 0], size[which, 1]
+    fx = np.where(face == 0, -0.5 * sx, np.where(face == 1, 0.5 * sx, t * sx))
+    fy = np.where(face == 2, -0.5 * sy, np.where(face == 3, 0.5 * sy, t * sy))
+    facade = np.stack((centre[which, 0] + fx + rs.randn(n_facade) * 0.01,
+                       centre[which, 1] + fy + rs.randn(n_facade) * 0.01,
+                       rs.rand(n_facade) * height[which]), axis=1)
+    points = np.concatenate((ground, facade), axis=0)
+    labels = np.concatenate((np.zeros(n_ground, dtype=np.int32), np.ones(n_facade, dtype=np.int32)))
+    order = rs.permutation(n)
+    return _round32(points[order]), labels[order]
+
+
 def morton_sort(points, edge_length):
     """order rows by the 63-bit Morton code of their `edge_length` cell (config 3 is stored this way:
     the layout a tiled LiDAR archive would hand over)."""
@@ -87,6 +121,8 @@ CONFIGS = {
     "c3_scene_10m": dict(kind="scene", n=10_000_000, extent=190.0, n_poles=2000, n_spheres=400,
                          seed=2, edges=[0.05, 0.10, 0.20, 0.40, 0.80],
                          radii=[0.15, 0.30, 0.60, 1.20, 2.40], morton=0.80),
+    "c4_lidar_50m": dict(kind="lidar", n=50_000_000, seed=3, edges=[0.05, 0.10, 0.20, 0.40, 0.80],
+                         radii=[0.15, 0.30, 0.60, 1.20, 2.40], knn_min=8),
 }
 
 
@@ -95,6 +131,9 @@ def make_config(name, n=None, seed_offset=0):
     point count (same generator, same density when the extent is scaled by the caller)."""
     cfg = dict(CONFIGS[name])
     cfg["seed"] = cfg["seed"] + 1000 * seed_offset
+    if cfg["kind"] == "lidar":
+        points, labels = lidar_cloud(n if n is not None else cfg["n"], seed=cfg["seed"])
+        return points, labels, list(cfg["edges"]), list(cfg["radii"])
     if n is not None and n != cfg["n"]:
         # keep the areal density: scale the extent with sqrt(n)
         cfg["extent"] = cfg["extent"] * np.sqrt(n / cfg["n"]) if cfg["kind"] == "scene" \

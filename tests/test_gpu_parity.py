@@ -532,3 +532,36 @@ def test_config3_full_size_properties():
     assert len(rows) > 5000
     want = oracle.process_fast(pts[rows], pts[outer], edges, radii, bounds=(lo, hi))
     assert_features_close(f[rows], want, pts)
+
+
+def test_config4_lidar_power_law_with_knn_fallback():
+    # config 4 at reduced size (2M of 50M points; same generator, so the far field is 25x sparser than
+    # at full size and the kNN fallback has plenty to do): power-law density, 5 scales, k_min = 8.
+    # checked: range invariants everywhere, an oracle comparison on a dense crop near the scanner and
+    # on a sparse crop far out (the oracle gets crop + halo and the global lattice extrema).
+    pts, _, edges, radii = synth.make_config("c4_lidar_50m", n=2_000_000)
+    k = synth.CONFIGS["c4_lidar_50m"]["knn_min"]
+    dev = torch.from_numpy(pts).cuda()
+    plain, info = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
+    full = multiscale.process_gpu(dev, dev, edges, radii, knn_min=k, knn_radius_factor=3.0)
+    p, f = plain.cpu().numpy(), full.cpu().numpy()
+    assert np.array_equal(p[:, ::4], f[:, ::4])
+    sparse_rows = p[:, 0] < k
+    assert sparse_rows.mean() > 0.02                       # the far field really is sparse
+    dense_rows = ~sparse_rows
+    assert np.array_equal(p[dense_rows, :4], f[dense_rows, :4])
+    for s in range(len(edges)):
+        n, l1, l2 = f[:, 4 * s], f[:, 4 * s + 2], f[:, 4 * s + 3]
+        assert n.min() >= 1 and n.max() <= 123
+        assert np.all(l1 <= 1.0 + 1e-12) and np.all(l2 <= l1 + 1e-12) and np.all(l2 >= -1e-12)
+    lo, hi = pts.min(0), pts.max(0)
+    for centre, half in (((3.0, 0.0), 1.5), ((90.0, 40.0), 12.0)):
+        d = np.abs(pts[:, :2] - np.asarray(centre))
+        inner = np.all(d <= half, axis=1)
+        outer = np.all(d <= half + 3.0 * 2.4 + 1.0, axis=1)
+        rows = np.nonzero(inner)[0][:6000]
+        assert len(rows) > 200
+        for s in (0, 2, 4):
+            lat_bounds = (lo, hi)
+            want = oracle.one_scale_fast(pts[rows], pts[outer], edges[s], radii[s], bounds=lat_bounds)
+            assert_features_close(p[rows, 4 * s:4 * s + 4], want, pts)
