@@ -754,10 +754,9 @@ __global__ void k_publish_info(const uint32_t* counters, int64_t* info)
 
 // ---- k-nearest-voxel fallback -------------------------------------------------------------------------
 // queries whose radius neighborhood has fewer than k voxels are re-evaluated on their k nearest occupied
-// voxel centres within rk (rk2 = rk*rk).  one lane per query, Chebyshev shells around the home cell; a
-// shell s is final once the k-th best distance is below (s + 1/2) cells, because every cell not yet
-// visited lies at least that far away.  rare path: direct index lookups, exact fp64 distances in the
-// reference's operation order, ties broken by the smaller voxel address.
+// voxel centres within rk (rk2 = rk*rk).  one lane per query; the lane walks the index leaves that
+// intersect the cube around its home cell that contains the ball of radius rk.  exact fp64 distances in
+// the reference's operation order, ties broken by the smaller voxel address.
 constexpr int NM_KNN_MAX = 16;
 
 struct KnnArgs {
@@ -785,72 +784,81 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
 
     double bd[NM_KNN_MAX];
     int64_t bc[NM_KNN_MAX];      // address-like code of the voxel: tie break and offsets
+    int32_t found = 0;
+    // two stages: a small cube first - most sparse neighborhoods find their k voxels just outside the
+    // radius - and the full cube only when the k-th best is not yet provably final (every cell outside
+    // a cube of half-width S is at least S + 1/2 cells away).
+    for (int stage = 0; stage < 2; ++stage) {
 #pragma unroll
     for (int t = 0; t < NM_KNN_MAX; ++t) {
         bd[t] = INFINITY;
         bc[t] = INT64_MAX;
     }
-    int32_t found = 0;
-    for (int32_t s = 0; s <= K.max_shell; ++s) {
-        for (int32_t dz = -s; dz <= s; ++dz) {
-            const int32_t gz = hz + dz;
-            if (gz < 0 || gz >= (1 << L.wz)) continue;
-            double d = qz - nm_centre(gz, L.min_z, L.edge, L.half_edge);
-            const double dz2 = d * d;
-            for (int32_t dy = -s; dy <= s; ++dy) {
-                const int32_t gy = hy + dy;
-                if (gy < 0 || gy >= (1 << L.wy)) continue;
-                d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
-                const double dy2 = d * d;
-                const bool face = (dz == -s || dz == s || dy == -s || dy == s);
-                const int32_t step = (face || s == 0) ? 1 : 2 * s;     // whole row, or its two ends
-                int32_t cached_sb = INT32_MIN;
-                uint32_t word = 0;
-                for (int32_t dx = -s; dx <= s; dx += step) {
-                    const int32_t gx = hx + dx;
-                    if (gx < 0 || gx >= (1 << L.wx)) continue;
-                    const int32_t sbx = gx >> NM_SBX_BITS;
-                    if (sbx != cached_sb) {
-                        cached_sb = sbx;
-                        const int32_t leaf = nm_hash_find(
-                            A.I, nm_sb_key((uint32_t)sbx, (uint32_t)(gy >> NM_SBY_BITS),
-                                           (uint32_t)(gz >> NM_SBZ_BITS), L));
-                        word = leaf >= 0
-                                   ? A.I.leaf[(size_t)leaf * NM_LEAF_WORDS + (gz & 7) * 8 + (gy & 7)]
-                                   : 0u;
-                    }
-                    if (!((word >> (gx & 31)) & 1u)) continue;
-                    d = qx - nm_centre(gx, L.min_x, L.edge, L.half_edge);
-                    double cd = (d * d + dy2) + dz2;
-                    if (!(cd <= K.rk2)) continue;
-                    // offsets from the home cell, biased, z high / x low: the same order as the
-                    // reference's voxel address, which is the tie break
-                    int64_t cc = ((int64_t)(dz + 1024) << 22) | ((int64_t)(dy + 1024) << 11) |
-                                 (int64_t)(dx + 1024);
-                    ++found;
-                    // insertion into the sorted top list (static indices: stays in registers)
+    found = 0;
+    // walk the leaves that intersect the cube of half-width S around the home cell: one hash lookup per
+    // leaf, then its 64 row words; only occupied cells cost a distance.  sparse neighborhoods (the only
+    // ones that get here) touch few leaves.
+    const int32_t S_small = (-A.dmin) + 2;
+    const int32_t S = (stage == 0 && S_small < K.max_shell) ? S_small : K.max_shell;
+    const int32_t x_lo = max(hx - S, 0), x_hi = min(hx + S, (1 << L.wx) - 1);
+    const int32_t y_lo = max(hy - S, 0), y_hi = min(hy + S, (1 << L.wy) - 1);
+    const int32_t z_lo = max(hz - S, 0), z_hi = min(hz + S, (1 << L.wz) - 1);
+    for (int32_t sbz = z_lo >> NM_SBZ_BITS; sbz <= (z_hi >> NM_SBZ_BITS); ++sbz)
+        for (int32_t sby = y_lo >> NM_SBY_BITS; sby <= (y_hi >> NM_SBY_BITS); ++sby)
+            for (int32_t sbx = x_lo >> NM_SBX_BITS; sbx <= (x_hi >> NM_SBX_BITS); ++sbx) {
+                const int32_t leaf = nm_hash_find(
+                    A.I, nm_sb_key((uint32_t)sbx, (uint32_t)sby, (uint32_t)sbz, L));
+                if (leaf < 0) continue;
+                // bits of this leaf's 32 x-cells that lie inside [x_lo, x_hi]
+                const int32_t bx0 = sbx << NM_SBX_BITS;
+                const int32_t lo_bit = max(x_lo - bx0, 0), hi_bit = min(x_hi - bx0, 31);
+                const uint32_t xmask = (hi_bit >= 31 ? ~0u : ((2u << hi_bit) - 1u)) & (~0u << lo_bit);
+                for (int32_t lz = 0; lz < 8; ++lz) {
+                    const int32_t gz = (sbz << NM_SBZ_BITS) + lz;
+                    if (gz < z_lo || gz > z_hi) continue;
+                    double d = qz - nm_centre(gz, L.min_z, L.edge, L.half_edge);
+                    const double dz2 = d * d;
+                    for (int32_t ly = 0; ly < 8; ++ly) {
+                        const int32_t gy = (sby << NM_SBY_BITS) + ly;
+                        if (gy < y_lo || gy > y_hi) continue;
+                        uint32_t word = A.I.leaf[(size_t)leaf * NM_LEAF_WORDS + lz * 8 + ly] & xmask;
+                        if (!word) continue;
+                        d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
+                        const double dy2 = d * d;
+                        while (word) {
+                            const int32_t bit = __ffs((int)word) - 1;
+                            word &= word - 1u;
+                            const int32_t gx = bx0 + bit;
+                            d = qx - nm_centre(gx, L.min_x, L.edge, L.half_edge);
+                            double cd = (d * d + dy2) + dz2;
+                            if (!(cd <= K.rk2)) continue;
+                            ++found;
+                            if (cd > bd[NM_KNN_MAX - 1]) continue;      // cannot enter the list
+                            // offsets from the home cell, biased, z high / x low: the same order as
+                            // the reference's voxel address, which is the tie break
+                            int64_t cc = ((int64_t)(gz - hz + 1024) << 22) |
+                                         ((int64_t)(gy - hy + 1024) << 11) | (int64_t)(gx - hx + 1024);
 #pragma unroll
-                    for (int t = 0; t < NM_KNN_MAX; ++t) {
-                        const bool before = cd < bd[t] || (cd == bd[t] && cc < bc[t]);
-                        const double td = before ? bd[t] : cd;
-                        const int64_t tc = before ? bc[t] : cc;
-                        bd[t] = before ? cd : bd[t];
-                        bc[t] = before ? cc : bc[t];
-                        cd = td;
-                        cc = tc;
+                            for (int t = 0; t < NM_KNN_MAX; ++t) {
+                                const bool before = cd < bd[t] || (cd == bd[t] && cc < bc[t]);
+                                const double td = before ? bd[t] : cd;
+                                const int64_t tc = before ? bc[t] : cc;
+                                bd[t] = before ? cd : bd[t];
+                                bc[t] = before ? cc : bc[t];
+                                cd = td;
+                                cc = tc;
+                            }
+                        }
                     }
                 }
             }
-        }
-        // k-th best so far
-        double kth = INFINITY;
+    double kth = INFINITY;
 #pragma unroll
-        for (int t = 0; t < NM_KNN_MAX; ++t)
-            if (t == K.k - 1) kth = bd[t];
-        const double reach = ((double)s + 0.5 - 1e-6) * L.edge;     // nothing unvisited is closer
-        if (kth <= reach * reach) break;
-        if (reach * reach > K.rk2) break;                            // nothing unvisited is in range
-    }
+    for (int t = 0; t < NM_KNN_MAX; ++t)
+        if (t == K.k - 1) kth = bd[t];
+    const double reach = ((double)S + 0.5 - 1e-6) * L.edge;
+    if (S >= K.max_shell || kth <= reach * reach) break;
+    }   // stage
     const int32_t use = found < K.k ? found : K.k;
     double n = 0, sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
 #pragma unroll
