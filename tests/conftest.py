@@ -24,8 +24,11 @@ def golden():
 # tolerances of the parity contract (BASELINE.json north_star):
 #   population: exact.  eigen-features: |a-b| <= 1e-5*|b| + 1e-9.
 #   centroid distance: 1e-9 relative plus the fp64 representation error of the coordinates
-#   themselves (the reference forms voxel centres in world coordinates, so at UTM-scale offsets its
-#   own value carries ~ulp(|coordinate|) of noise).
+#   themselves: the reference forms every voxel centre in world coordinates (up to 2 ulp of the
+#   coordinate each: cell*e, + min_corner, + e/2), sums k of them (numpy.mean) and subtracts; at
+#   UTM-scale offsets its own value therefore carries tens of ulp(|coordinate|) of noise, while the GPU
+#   path works in exact integer offsets from the home voxel.  a randomised sweep (tools/fuzz_parity.py)
+#   saw differences up to 20 ulp; 64 ulp are allowed.
 def assert_features_close(got, want, points, eig_rtol=1e-5, eig_atol=1e-9):
     got = np.asarray(got)
     want = np.asarray(want)
@@ -34,7 +37,7 @@ def assert_features_close(got, want, points, eig_rtol=1e-5, eig_atol=1e-9):
     for s in range(want.shape[1] // 4):
         g, w = got[:, 4 * s:4 * s + 4], want[:, 4 * s:4 * s + 4]
         assert np.array_equal(g[:, 0], w[:, 0]), "population differs at scale %d" % s
-        tol = 1e-9 * np.abs(w[:, 1]) + 16 * coord_ulp + 1e-12
+        tol = 1e-9 * np.abs(w[:, 1]) + 64 * coord_ulp + 1e-12
         bad = np.abs(g[:, 1] - w[:, 1]) > tol
         assert not bad.any(), "centroid differs at scale %d: max err %g" % (
             s, np.abs(g[:, 1] - w[:, 1]).max())

@@ -1,0 +1,75 @@
+"""randomised parity sweep: GPU (through the C ABI) against the oracle on many small random cases.
+not part of the test suite (minutes of oracle time); run on the GPU box:  python tools/fuzz_parity.py 200"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from nimrud_amd import synth
+from nimrud_amd.minimal import multiscale
+from oracle import nimrud_oracle as oracle
+from conftest import assert_features_close
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+t0 = time.time()
+worst = 0.0
+for case in range(n_cases):
+    kind = rs.randint(0, 6)
+    n = int(rs.randint(200, 20000))
+    if kind == 0:
+        pts = synth.uniform_cloud(n, extent=float(rs.uniform(0.5, 8.0)), seed=int(rs.randint(1 << 30)))
+    elif kind == 1:
+        pts, _ = synth.scene_cloud(n, extent=float(rs.uniform(2.0, 20.0)), n_poles=int(rs.randint(1, 8)),
+                                   n_spheres=int(rs.randint(1, 4)), seed=int(rs.randint(1 << 30)))
+    elif kind == 2:
+        pts, _ = synth.lidar_cloud(n, seed=int(rs.randint(1 << 30)), r_max=float(rs.uniform(5, 60)),
+                                   n_boxes=int(rs.randint(2, 30)))
+    elif kind == 3:      # lattice-aligned points: exact ties on the radius
+        step = float(rs.choice([0.125, 0.25, 0.5, 1.0]))
+        pts = rs.randint(0, 14, size=(n, 3)).astype(np.float64) * step
+        pts = np.unique(pts, axis=0)
+        pts = np.concatenate((pts, pts[: len(pts) // 3]))
+    elif kind == 4:      # far from the origin, not fp32-representable
+        pts = synth.uniform_cloud(n, extent=float(rs.uniform(1.0, 5.0)), seed=int(rs.randint(1 << 30)))
+        pts = pts * 1.0000001 + rs.uniform(-1, 1, size=3) * 10.0 ** rs.randint(2, 8)
+    else:                # anisotropic slab
+        pts = rs.rand(n, 3) * np.array([rs.uniform(1, 30), rs.uniform(1, 30), rs.uniform(0.05, 2.0)])
+    n_scales = int(rs.randint(1, 4))
+    if kind == 3:
+        edges = [step * float(rs.choice([1.0, 2.0])) for _ in range(n_scales)]
+        radii = [e * float(rs.choice([1.0, 2.0, 3.0, 1.5])) for e in edges]
+    else:
+        edges = [float(rs.uniform(0.03, 0.6)) for _ in range(n_scales)]
+        radii = [e * float(rs.choice([3.0, 3.0, rs.uniform(0.6, 4.4), 2.0, 1.0])) for e in edges]
+    if len(np.unique(pts, axis=0)) < 2:
+        continue
+    separate = rs.rand() < 0.3
+    if separate:
+        q = pts[rs.randint(0, len(pts), size=max(10, n // 3))] + rs.randn(max(10, n // 3), 3) * edges[0]
+        if rs.rand() < 0.3:
+            q[:5] += 1000.0
+    else:
+        q = pts
+    try:
+        lat_ok = all(np.all(oracle.Lattice(pts, e).widths >= 1) for e in edges)
+    except ValueError:
+        lat_ok = False
+    if not lat_ok:
+        continue
+    want = oracle.process_fast(q, pts, edges, radii)
+    dq = torch.from_numpy(np.ascontiguousarray(q)).cuda()
+    dp = dq if not separate else torch.from_numpy(np.ascontiguousarray(pts)).cuda()
+    per_scale = bool(rs.rand() < 0.3)
+    got = multiscale.process_gpu(dq, dp, edges, radii, per_scale=per_scale).cpu().numpy()
+    try:
+        assert_features_close(got, want, np.concatenate((pts, q[np.abs(q).max(1) < 1e6])))
+    except AssertionError as err:
+        print("CASE %d FAILED kind=%d n=%d edges=%s radii=%s separate=%s per_scale=%s: %s"
+              % (case, kind, n, edges, radii, separate, per_scale, str(err)[:200]), flush=True)
+        np.savez("gpurun_out/fuzz_fail_%d.npz" % case, pts=pts, q=q, edges=edges, radii=radii)
+        continue
+    eig = np.abs(got - want)[:, [c for s in range(n_scales) for c in (4 * s + 2, 4 * s + 3)]]
+    worst = max(worst, float(eig.max()) if eig.size else 0.0)
+    if case % 20 == 0:
+        print("case %d ok (kind %d, n %d, scales %d) %.0f s" % (case, kind, n, n_scales, time.time() - t0), flush=True)
+print("done: %d cases, worst eigen-feature |err| %.3g, %.0f s" % (n_cases, worst, time.time() - t0))
