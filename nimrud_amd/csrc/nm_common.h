@@ -115,10 +115,17 @@ static inline int validate_lattice(nm_ctx* ctx, const nm_lattice* lat)
     return NM_OK;
 }
 
+// one slot of the superblock directory.  key and value sit in one 16-byte entry so that a probe is a
+// single load (the builders are latency-bound: every dependent memory round trip counts).
+struct HashEntry {
+    uint64_t key;            // superblock key, NM_HASH_EMPTY = free
+    uint32_t val;            // leaf number
+    uint32_t pad;
+};
+
 // the occupancy index of one scale (all pointers into the caller's workspace)
 struct IndexDev {
-    uint64_t* hash_key;      // open-addressing table of superblock keys (NM_HASH_EMPTY = free)
-    uint32_t* hash_val;      // leaf number of the key in the same slot
+    struct HashEntry* hash;  // open-addressing table: one 16-byte entry per slot, key + leaf number
     uint32_t hash_mask;      // capacity - 1 (capacity is a power of two)
     uint32_t* leaf;          // leaves, NM_LEAF_WORDS words each
     uint32_t leaf_capacity;  // leaves the workspace has room for
@@ -180,8 +187,9 @@ __device__ __forceinline__ int32_t nm_hash_find(const IndexDev& I, uint64_t key)
 {
     uint32_t slot = nm_hash64(key) & I.hash_mask;
     for (;;) {
-        uint64_t k = I.hash_key[slot];
-        if (k == key) return (int32_t)I.hash_val[slot];
+        const uint4 e = *(const uint4*)&I.hash[slot];          // one 16-byte load: key and value
+        const uint64_t k = (uint64_t)e.x | ((uint64_t)e.y << 32);
+        if (k == key) return (int32_t)e.z;
         if (k == NM_HASH_EMPTY) return -1;
         slot = (slot + 1) & I.hash_mask;
     }

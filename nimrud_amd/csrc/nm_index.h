@@ -5,7 +5,7 @@
 struct IndexLayout {
     uint32_t leaf_capacity;
     uint32_t hash_capacity;
-    size_t hash_key_bytes, hash_val_bytes, leaf_bytes, counter_bytes, total;
+    size_t hash_bytes, leaf_bytes, counter_bytes, total;
 };
 
 size_t nm_sort_pairs_temp_bytes(int64_t n);

@@ -424,10 +424,10 @@ __global__ __launch_bounds__(256) void k_index_leaves(const uint64_t* __restrict
                 uint32_t slot = nm_hash64(sb) & I.hash_mask;
                 for (;;) {
                     const unsigned long long prev =
-                        atomicCAS((unsigned long long*)&I.hash_key[slot],
+                        atomicCAS((unsigned long long*)&I.hash[slot].key,
                                   (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
                     if (prev == NM_HASH_EMPTY) {
-                        I.hash_val[slot] = idx;
+                        I.hash[slot].val = idx;
                         break;
                     }
                     slot = (slot + 1) & I.hash_mask;
@@ -505,11 +505,10 @@ void nm_index_layout(const LatticeDev& L, int64_t n_search, IndexLayout* out)
     while (hcap < cap * 2) hcap <<= 1;
     out->leaf_capacity = (uint32_t)cap;
     out->hash_capacity = (uint32_t)hcap;
-    out->hash_key_bytes = align_up((size_t)hcap * 8);
-    out->hash_val_bytes = align_up((size_t)hcap * 4);
+    out->hash_bytes = align_up((size_t)hcap * sizeof(HashEntry));
     out->leaf_bytes = align_up((size_t)cap * NM_LEAF_WORDS * 4);
     out->counter_bytes = 256;
-    out->total = out->hash_key_bytes + out->hash_val_bytes + out->leaf_bytes + out->counter_bytes;
+    out->total = out->hash_bytes + out->leaf_bytes + out->counter_bytes;
 }
 
 int nm_sort_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const LatticeDev& L,
@@ -527,13 +526,12 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
 {
     char* w = (char*)index_mem;
     IndexDev I;
-    I.hash_key = (uint64_t*)w;      w += lay.hash_key_bytes;
-    I.hash_val = (uint32_t*)w;      w += lay.hash_val_bytes;
+    I.hash = (HashEntry*)w;         w += lay.hash_bytes;
     I.leaf = (uint32_t*)w;          w += lay.leaf_bytes;
     I.counters = (uint32_t*)w;
     I.hash_mask = lay.hash_capacity - 1;
     I.leaf_capacity = lay.leaf_capacity;
-    NM_HIP(ctx, hipMemsetAsync(I.hash_key, 0xFF, (size_t)lay.hash_capacity * 8, s));
+    NM_HIP(ctx, hipMemsetAsync(I.hash, 0xFF, (size_t)lay.hash_capacity * sizeof(HashEntry), s));
     NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
     int blocks = (int)((n + INDEX_CHUNK - 1) / INDEX_CHUNK);
     k_index_leaves<<<blocks, 256, 0, s>>>(key_sorted, n, I);
@@ -630,14 +628,14 @@ __global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restr
         if (valid && sb != prev) {
             uint32_t slot = nm_hash64(sb) & I.hash_mask;
             for (;;) {
-                const uint64_t peek = I.hash_key[slot];
+                const uint64_t peek = I.hash[slot].key;
                 if (peek == sb) break;
                 if (peek != NM_HASH_EMPTY) {
                     slot = (slot + 1) & I.hash_mask;
                     continue;
                 }
                 const unsigned long long seen =
-                    atomicCAS((unsigned long long*)&I.hash_key[slot],
+                    atomicCAS((unsigned long long*)&I.hash[slot].key,
                               (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
                 if (seen == NM_HASH_EMPTY) {
                     won_slot[atomicAdd(&won_count, 1u)] = slot;
@@ -662,7 +660,7 @@ __global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restr
         uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
 #pragma unroll
         for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
-        I.hash_val[won_slot[t]] = idx;
+        I.hash[won_slot[t]].val = idx;
     }
 }
 
@@ -688,14 +686,14 @@ __global__ __launch_bounds__(256) void k_index_insert(const uint64_t* __restrict
             for (;;) {
                 // a plain look first: once a superblock is in the table every later run of it costs
                 // a (cached) load instead of an atomic.  a stale "empty" only means we try the CAS.
-                const uint64_t peek = I.hash_key[slot];
+                const uint64_t peek = I.hash[slot].key;
                 if (peek == sb) break;
                 if (peek != NM_HASH_EMPTY) {
                     slot = (slot + 1) & I.hash_mask;
                     continue;
                 }
                 const unsigned long long seen =
-                    atomicCAS((unsigned long long*)&I.hash_key[slot],
+                    atomicCAS((unsigned long long*)&I.hash[slot].key,
                               (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
                 if (seen == NM_HASH_EMPTY) {
                     won_slot[atomicAdd(&won_count, 1u)] = slot;
@@ -720,17 +718,15 @@ __global__ __launch_bounds__(256) void k_index_insert(const uint64_t* __restrict
         uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
 #pragma unroll
         for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
-        I.hash_val[won_slot[t]] = idx;
+        I.hash[won_slot[t]].val = idx;
     }
 }
 
 __global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restrict__ key, int64_t n,
                                                         IndexDev I)
 {
-    __shared__ uint32_t wcells[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
-    uint32_t cells = 0;
     for (int it = 0; it < INDEX_ITERS; ++it) {
         const int64_t i = wave_lo + it * 64 + lane;
         if (wave_lo + it * 64 >= n) break;
@@ -754,25 +750,33 @@ __global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restri
             if (lane - off >= seg_start) bits |= other;
         }
         const bool tail = valid && (lane == 63 || ((rowm >> (lane + 1)) & 1ull) || i + 1 >= n);
-        uint32_t fresh = 0;
         if (tail && leaf >= 0) {
             const uint32_t local = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
-            uint32_t* word = &I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)];
-            // a plain look first: at coarse scales most runs find their voxels already set (a stale
-            // value can only cause a redundant atomic, never a missed one)
-            if ((*word & bits) != bits) {
-                const uint32_t old = atomicOr(word, bits);
-                fresh = (uint32_t)__popc(bits & ~old);  // voxels nobody had set before
-            }
+            // no return value wanted: the wave does not wait for the atomic.  M is counted afterwards
+            // from the leaves (k_count_voxels)
+            atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)], bits);
         }
-        cells += fresh;      // per lane; summed over the wave once, after the loop
+    }
+}
+
+// M = number of set bits in the allocated leaves (counters[0] of them)
+__global__ __launch_bounds__(256) void k_count_voxels(IndexDev I)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t n_leaves = min(I.counters[0], I.leaf_capacity);
+    const uint64_t words = (uint64_t)n_leaves * NM_LEAF_WORDS / 4;     // as uint4
+    uint32_t c = 0;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < words;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = ((const uint4*)I.leaf)[t];
+        c += (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cells += __shfl_xor(cells, off);
-    if (lane == 0) wcells[w] = cells;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t t = wcells[0] + wcells[1] + wcells[2] + wcells[3];
+        const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         if (t) atomicAdd(&I.counters[1], t);
     }
 }
@@ -841,18 +845,18 @@ int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const L
 {
     char* w = (char*)index_mem;
     IndexDev I;
-    I.hash_key = (uint64_t*)w;      w += lay.hash_key_bytes;
-    I.hash_val = (uint32_t*)w;      w += lay.hash_val_bytes;
+    I.hash = (HashEntry*)w;         w += lay.hash_bytes;
     I.leaf = (uint32_t*)w;          w += lay.leaf_bytes;
     I.counters = (uint32_t*)w;
     I.hash_mask = lay.hash_capacity - 1;
     I.leaf_capacity = lay.leaf_capacity;
-    NM_HIP(ctx, hipMemsetAsync(I.hash_key, 0xFF, (size_t)lay.hash_capacity * 8, s));
+    NM_HIP(ctx, hipMemsetAsync(I.hash, 0xFF, (size_t)lay.hash_capacity * sizeof(HashEntry), s));
     NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
     nm_profile_mark(ctx, s);      // end of the "keys" stage (order build), start of the "index" stage
     const int blocks = (int)((n + INDEX_CHUNK - 1) / INDEX_CHUNK);
     k_index_keys_insert<<<blocks, 256, 0, s>>>(sorted_xyz, n, L, key_buf, I);
     k_index_bits_any<<<blocks, 256, 0, s>>>(key_buf, n, I);
+    k_count_voxels<<<512, 256, 0, s>>>(I);
     NM_HIP(ctx, hipGetLastError());
     *out = I;
     return NM_OK;
