@@ -550,10 +550,11 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
 // but neighbours in the stream are still neighbours in space, so runs of equal superblock / equal row
 // word are long.  duplicates are therefore squeezed out inside each wave (compare with the previous
 // key), and what is left goes through the hash table with atomics:
-//   k_index_insert   run heads CAS their superblock key into the table; a block's winners get leaf
-//                    numbers from ONE counter bump per block, zero their leaf and publish it
-//   k_index_bits_any run tails atomicOr the run's bits into the leaf; bits that were not set before
-//                    are the new voxels, which gives M without a sorted unique pass
+//   k_index_keys_insert  cell keys of this scale (stored for the next kernel); run heads CAS their
+//                        superblock key into the table; a block's winners get leaf numbers from ONE
+//                        counter bump per block, zero their leaf and publish it
+//   k_index_bits_any     run tails atomicOr the run's bits into the leaf (no return value awaited)
+//   k_count_voxels       M = set bits of the allocated leaves
 // ---------------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_gather_xyz(const double* __restrict__ xyz, int64_t n,
@@ -569,22 +570,6 @@ __global__ __launch_bounds__(256) void k_gather_xyz(const double* __restrict__ x
     out[i * 3 + 2] = p[2];
 }
 
-__global__ __launch_bounds__(256) void k_cell_keys_only(const double* __restrict__ xyz, int64_t n,
-                                                        int64_t stride, LatticeDev L,
-                                                        uint64_t* __restrict__ key)
-{
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double* p = xyz + i * stride;
-    int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
-    int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
-    int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
-    cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
-    cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
-    cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
-    key[i] = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
-}
-
 __device__ __forceinline__ uint64_t nm_point_key(const double* __restrict__ p, const LatticeDev& L)
 {
     int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
@@ -596,8 +581,8 @@ __device__ __forceinline__ uint64_t nm_point_key(const double* __restrict__ p, c
     return nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
 }
 
-// k_cell_keys_only + k_index_insert in one pass over the coordinate stream: the keys are computed,
-// stored for k_index_bits_any, and the run heads go to the hash table.
+// one pass over the coordinate stream: the keys are computed and stored for k_index_bits_any, and the
+// run heads go to the hash table.
 __global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restrict__ xyz, int64_t n,
                                                            LatticeDev L, uint64_t* __restrict__ key,
                                                            IndexDev I)
@@ -628,64 +613,6 @@ __global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restr
         if (valid && sb != prev) {
             uint32_t slot = nm_hash64(sb) & I.hash_mask;
             for (;;) {
-                const uint64_t peek = I.hash[slot].key;
-                if (peek == sb) break;
-                if (peek != NM_HASH_EMPTY) {
-                    slot = (slot + 1) & I.hash_mask;
-                    continue;
-                }
-                const unsigned long long seen =
-                    atomicCAS((unsigned long long*)&I.hash[slot].key,
-                              (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
-                if (seen == NM_HASH_EMPTY) {
-                    won_slot[atomicAdd(&won_count, 1u)] = slot;
-                    break;
-                }
-                if (seen == sb) break;
-                slot = (slot + 1) & I.hash_mask;
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t total = won_count;
-    if (total == 0) return;
-    if (threadIdx.x == 0) leaf_base = atomicAdd(&I.counters[0], total);
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
-        const uint32_t idx = leaf_base + t;
-        if (idx >= I.leaf_capacity) {
-            I.counters[2] = 1u;
-            continue;
-        }
-        uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
-#pragma unroll
-        for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
-        I.hash[won_slot[t]].val = idx;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_index_insert(const uint64_t* __restrict__ key, int64_t n,
-                                                      IndexDev I)
-{
-    __shared__ uint32_t won_slot[INDEX_CHUNK];
-    __shared__ uint32_t won_count;
-    __shared__ uint32_t leaf_base;
-    if (threadIdx.x == 0) won_count = 0u;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
-    for (int it = 0; it < INDEX_ITERS; ++it) {
-        const int64_t i = wave_lo + it * 64 + lane;
-        if (wave_lo + it * 64 >= n) break;
-        const bool valid = i < n;
-        const uint64_t sb = valid ? (key[i] >> NM_LOCAL_BITS) : 0ull;
-        // only the first key of a run of equal superblocks goes to the table
-        const uint64_t prev = (valid && i > 0) ? (key[i - 1] >> NM_LOCAL_BITS) : ~sb;
-        if (valid && sb != prev) {
-            uint32_t slot = nm_hash64(sb) & I.hash_mask;
-            for (;;) {
-                // a plain look first: once a superblock is in the table every later run of it costs
-                // a (cached) load instead of an atomic.  a stale "empty" only means we try the CAS.
                 const uint64_t peek = I.hash[slot].key;
                 if (peek == sb) break;
                 if (peek != NM_HASH_EMPTY) {

@@ -149,3 +149,62 @@ class ForestModel(object):
         if as_torch:
             return label
         return self.classes[label.cpu().numpy()]
+
+
+# ---- training-side glue --------------------------------------------------
+# host logic around the GPU evaluator: how the reference's workbench gets from a labelled feature matrix
+# to a fitted forest and a score.  training itself stays in scikit-learn, as in the reference
+# (prototypes/apc.py:1463, clf.fit at :969); only evaluation is on the hot path.
+
+def balanced_split(labels, seed=0):
+    """balanced training / validation index sets (prototypes/apc.py:895-917): with m = floor(half the
+    population of the rarest class), every class contributes m rows to each set, drawn without
+    replacement.  labels are integers 0..C-1; returns (train_idx, valid_idx)."""
+    labels = np.asarray(labels)
+    rs = np.random.RandomState(seed)
+    classes = np.unique(labels)
+    m = int(min((labels == c).sum() for c in classes) // 2)
+    train, valid = [], []
+    for c in classes:
+        idx = rs.permutation(np.nonzero(labels == c)[0])
+        train.append(idx[:m])
+        valid.append(idx[m:2 * m])
+    return np.concatenate(train), np.concatenate(valid)
+
+
+def train_forest(features, labels, n_estimators=32, max_depth=12, criterion="gini", bootstrap=True,
+                 n_jobs=6, random_state=0, device=None):
+    """fit sklearn's RandomForestClassifier (the reference's 'rf' choice, apc.py:1463: n_estimators,
+    criterion, bootstrap, n_jobs=6) on host arrays and return (ForestModel on the GPU, fitted clf)."""
+    from sklearn.ensemble import RandomForestClassifier
+    x = features.cpu().numpy() if isinstance(features, torch.Tensor) else np.asarray(features)
+    y = labels.cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+    clf = RandomForestClassifier(n_estimators=n_estimators, max_depth=max_depth, criterion=criterion,
+                                 bootstrap=bootstrap, n_jobs=n_jobs, random_state=random_state)
+    clf.fit(x, y)
+    return ForestModel.from_sklearn(clf, device=device), clf
+
+
+def confusion_matrix(predicted, truth, n_classes=None):
+    """full multiclass confusion matrix (prototypes/ml.py:521-552 mc_confusion): entry [row, col] =
+    number of points of known class `col` that received label `row`.  integer labels 0..n-1; computed on
+    the device when given GPU tensors."""
+    if isinstance(predicted, torch.Tensor) or isinstance(truth, torch.Tensor):
+        p = torch.as_tensor(predicted).to(torch.int64).reshape(-1)
+        t = torch.as_tensor(truth).to(p.device).to(torch.int64).reshape(-1)
+        n = int(n_classes) if n_classes is not None else int(max(p.max().item(), t.max().item())) + 1
+        flat = torch.bincount(p * n + t, minlength=n * n)
+        return flat.reshape(n, n).cpu().numpy().astype(np.float64)
+    p = np.asarray(predicted).astype(np.int64).ravel()
+    t = np.asarray(truth).astype(np.int64).ravel()
+    n = int(n_classes) if n_classes is not None else int(max(p.max(), t.max())) + 1
+    return np.bincount(p * n + t, minlength=n * n).reshape(n, n).astype(np.float64)
+
+
+def classify_cloud(cloud, edge_lengths, radii, model, **kwargs):
+    """features + forest in one go for a cloud resident on the GPU (BASELINE config 5): returns
+    (labels int32 GPU tensor of class positions, (N, 4*S) feature tensor)."""
+    from nimrud_amd.minimal import multiscale
+    feats = multiscale.process_gpu(cloud, cloud, edge_lengths, radii, **kwargs)
+    _, label, _ = model._eval(feats, False, True)
+    return label, feats

@@ -132,3 +132,21 @@ def test_forest_flattening_matches_sklearn(golden):
     xe = rs.rand(300, 6)
     assert np.abs(oracle.forest_predict_proba(model, xe) - clf.predict_proba(xe)).max() < 1e-15
     assert np.array_equal(oracle.forest_predict(model, xe), clf.predict(xe))
+
+
+def test_training_glue_host_side():
+    # apc.py:895-917 balanced sampling, ml.py:521-552 mc_confusion
+    from nimrud_amd.minimal import classification
+    labels = np.array([0] * 50 + [1] * 21 + [2] * 200)
+    tr, va = classification.balanced_split(labels, seed=1)
+    assert len(tr) == len(va) == 3 * 10 and not set(tr) & set(va)
+    for c in range(3):
+        assert (labels[tr] == c).sum() == 10 and (labels[va] == c).sum() == 10
+    lies = np.array([0, 1, 1, 2, 2, 2, 0])
+    truth = np.array([0, 1, 2, 2, 2, 0, 0])
+    conf = classification.confusion_matrix(lies, truth)
+    want = np.zeros((3, 3))
+    for row in range(3):
+        for col in range(3):
+            want[row, col] = ((lies == row) * (truth == col)).sum()
+    assert np.array_equal(conf, want)

@@ -565,3 +565,21 @@ def test_config4_lidar_power_law_with_knn_fallback():
             lat_bounds = (lo, hi)
             want = oracle.one_scale_fast(pts[rows], pts[outer], edges[s], radii[s], bounds=lat_bounds)
             assert_features_close(p[rows, 4 * s:4 * s + 4], want, pts)
+
+
+def test_classify_cloud_end_to_end():
+    # config 5 in miniature: features -> balanced split -> sklearn fit -> GPU forest -> confusion
+    pts, labels = synth.scene_cloud(60000, extent=14.0, n_poles=12, n_spheres=4, seed=151)
+    dev = torch.from_numpy(pts).cuda()
+    edges, radii = [0.1, 0.2, 0.4], [0.3, 0.6, 1.2]
+    feats = multiscale.process_gpu(dev, dev, edges, radii)
+    tr, va = classification.balanced_split(labels, seed=0)
+    model, clf = classification.train_forest(feats[torch.from_numpy(tr).cuda()], labels[tr],
+                                             n_estimators=16, max_depth=10, n_jobs=4)
+    pred, feats2 = classification.classify_cloud(dev, edges, radii, model)
+    assert torch.equal(feats, feats2)
+    got = model.classes[pred.cpu().numpy()]
+    assert np.array_equal(got[va], clf.predict(feats[torch.from_numpy(va).cuda()].cpu().numpy()))
+    conf = classification.confusion_matrix(pred[torch.from_numpy(va).cuda()],
+                                           torch.from_numpy(labels[va]).cuda(), n_classes=3)
+    assert conf.sum() == len(va) and np.trace(conf) / conf.sum() > 0.9
