@@ -210,7 +210,7 @@ def main():
                 "search_points_incl_halo": int(n_local_search),
                 "halo_points_exchanged_per_step": int(total_halo),
                 "collectives": "none" if world == 1 else
-                               "all-reduce(6 f64) + all-gather(6 f64) + 2x all-to-all-v per step",
+                               "all-gather(6 f64/rank) + all-to-all(counts) + all-to-all-v(halo rows) per step",
             },
             "roofline": {
                 "bound": "hbm",

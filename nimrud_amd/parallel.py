@@ -7,9 +7,10 @@ query tile with a search tile grown by the largest scale (prototypes/mso.py:892-
 prototypes/apc.py:399-428,595, utils/geometry.py:203-253).  here:
 
   1. every rank holds one tile of the cloud (its rows are its query points).
-  2. all-reduce (MIN/MAX, 6 doubles): the GLOBAL per-axis extrema, so that every rank builds the same
-     lattice as a single-process run on the whole cloud (geometry.py:37: min_corner = min - e/2).
-  3. all-gather (6 doubles per rank): every tile's bounding box.
+  2. all-gather (6 doubles per rank): every tile's bounding box.  their per-axis min / max are the
+     GLOBAL extrema, so every rank builds the same lattice as a single-process run on the whole cloud
+     (geometry.py:37: min_corner = min - e/2).
+  3. all-to-all (one int64 per pair): how many halo rows each pair will exchange.
   4. all-to-all-v: each rank sends rank j the points of its tile that lie within
      margin = max_s(radius_s + sqrt(3)/2 * edge_s) of j's box.  a voxel centre within radius of one of
      j's query points can only be occupied by points that close, so after the exchange every voxel j
@@ -139,14 +140,18 @@ def exchange_halo(plan):
         mm = local.cpu().numpy()
         return mm[:3], mm[3:], 0
     cdev = torch.device("cpu") if plan.stage_on_host else dev    # where the collectives run
-    local_c = local.to(cdev)
-    glo = local_c[:3].clone()
-    ghi = local_c[3:].clone()
-    dist.all_reduce(glo, op=dist.ReduceOp.MIN, group=group)
-    dist.all_reduce(ghi, op=dist.ReduceOp.MAX, group=group)
-    box_list = [torch.empty(6, dtype=torch.float64, device=cdev) for _ in range(plan.world)]
-    dist.all_gather(box_list, local_c.contiguous(), group=group)
-    boxes = torch.stack(box_list).to(dev)
+    local_c = local.to(cdev).contiguous()
+    # one all-gather serves both purposes: every tile's box, and (their min / max) the global extrema
+    gathered = torch.empty((plan.world, 6), dtype=torch.float64, device=cdev)
+    try:
+        dist.all_gather_into_tensor(gathered.reshape(-1), local_c, group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        box_list = [torch.empty(6, dtype=torch.float64, device=cdev) for _ in range(plan.world)]
+        dist.all_gather(box_list, local_c, group=group)
+        gathered = torch.stack(box_list)
+    glo = gathered[:, :3].min(dim=0).values
+    ghi = gathered[:, 3:].max(dim=0).values
+    boxes = gathered.to(dev).clone()
     boxes[:, :3] -= plan.margin
     boxes[:, 3:] += plan.margin
     send_counts = be.halo_count(cloud, boxes, plan.rank).to(cdev)
