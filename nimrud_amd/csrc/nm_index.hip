@@ -741,10 +741,25 @@ __global__ __launch_bounds__(256) void k_order_keys(const double* __restrict__ x
     cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
     // the order only has to be spatially coherent: blocks of 4x4x4 finest cells are left unordered
     // inside, which takes 6 bits (one radix pass at this size) off the sort
-    key[i] = morton ? (nm_spread3((uint32_t)cx >> NM_ORDER_DROP) |
-                       (nm_spread3((uint32_t)cy >> NM_ORDER_DROP) << 1) |
-                       (nm_spread3((uint32_t)cz >> NM_ORDER_DROP) << 2))
-                    : nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
+    uint64_t k;
+    if (morton) {
+        // Z-order with the always-zero bits squeezed out: bit b of every axis that HAS a bit b, lowest
+        // bits first.  same order as the plain 3-way interleave, but only wx+wy+wz key bits to sort
+        // (one radix pass fewer when the axes have different widths)
+        const uint32_t ux = (uint32_t)cx >> NM_ORDER_DROP, uy = (uint32_t)cy >> NM_ORDER_DROP,
+                       uz = (uint32_t)cz >> NM_ORDER_DROP;
+        const int bx = L.wx - NM_ORDER_DROP, by = L.wy - NM_ORDER_DROP, bz = L.wz - NM_ORDER_DROP;
+        k = 0ull;
+        int pos = 0;
+        for (int b = 0; b < 21; ++b) {
+            if (b < bx) k |= (uint64_t)((ux >> b) & 1u) << pos++;
+            if (b < by) k |= (uint64_t)((uy >> b) & 1u) << pos++;
+            if (b < bz) k |= (uint64_t)((uz >> b) & 1u) << pos++;
+        }
+    } else {
+        k = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
+    }
+    key[i] = k;
     val[i] = (uint32_t)i;
 }
 
@@ -755,8 +770,10 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
     int wmax = L.wx > L.wy ? L.wx : L.wy;
     if (L.wz > wmax) wmax = L.wz;
     const int morton = wmax <= 21;
-    const int wsort = wmax > NM_ORDER_DROP ? wmax - NM_ORDER_DROP : 1;
-    const unsigned bits = morton ? (unsigned)(3 * wsort) : (unsigned)L.keybits;
+    int sort_bits = 0;
+    for (int w : {L.wx, L.wy, L.wz}) sort_bits += w > NM_ORDER_DROP ? w - NM_ORDER_DROP : 0;
+    if (sort_bits < 1) sort_bits = 1;
+    const unsigned bits = morton ? (unsigned)sort_bits : (unsigned)L.keybits;
     k_order_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, morton, key_tmp,
                                                        val_tmp);
     NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp,
