@@ -583,3 +583,14 @@ def test_classify_cloud_end_to_end():
     conf = classification.confusion_matrix(pred[torch.from_numpy(va).cuda()],
                                            torch.from_numpy(labels[va]).cuda(), n_classes=3)
     assert conf.sum() == len(va) and np.trace(conf) / conf.sum() > 0.9
+
+
+def test_verbose_mode_prints_like_the_reference(capsys):
+    # multiscale.py:47-65: per-scale and total timing lines
+    pts = synth.uniform_cloud(3000, extent=2.0, seed=161)
+    quiet = multiscale.process_single_core(pts, pts, [0.2, 0.4], [0.6, 1.2])
+    loud = multiscale.process_single_core(pts, pts, [0.2, 0.4], [0.6, 1.2], verbose=True)
+    assert np.array_equal(quiet, loud)
+    text = capsys.readouterr().out
+    assert text.count("this scale took") == 2 and "final rate of" in text
+    assert "querying 3000 points against a search space of" in text
