@@ -63,10 +63,13 @@ def _scale_into(rt, query, search, shared, lo, hi, edge_length, radius, out_view
         _device.ptr(work), work.numel(), rt.stream()))
 
 
-def _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info):
+def _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info, knn_min=0,
+                 knn_radius_factor=3.0):
     """enqueue the whole ladder in one library call (nm_multiscale_features): the cloud is sorted
     once, every scale's index is built from that order."""
     from nimrud_amd import _ffi
+    # the fallback switch is context state in the C ABI: always set it, so no call inherits another's
+    rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
     n_scales = len(edge_lengths)
     lats = (_ffi.NmLattice * n_scales)()
     for s, e in enumerate(edge_lengths):
@@ -116,7 +119,8 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
     lo, hi = _device.cloud_bounds(rt, search)
     rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
     if not (verbose or per_scale):
-        _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info)
+        _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info,
+                     knn_min=knn_min, knn_radius_factor=knn_radius_factor)
         edge_lengths_loop = []
     else:
         edge_lengths_loop = list(zip(edge_lengths, radii))
