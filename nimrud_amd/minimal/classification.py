@@ -147,7 +147,8 @@ class ForestModel(object):
         """(N,) class labels (argmax of predict_proba, first maximum wins)."""
         _, label, as_torch = self._eval(features, False, True)
         if as_torch:
-            return label
+            classes = torch.as_tensor(self.classes, device=label.device)
+            return classes[label.to(torch.int64)]
         return self.classes[label.cpu().numpy()]
 
 

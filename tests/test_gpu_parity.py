@@ -580,6 +580,7 @@ def test_classify_cloud_end_to_end():
     assert torch.equal(feats, feats2)
     got = model.classes[pred.cpu().numpy()]
     assert np.array_equal(got[va], clf.predict(feats[torch.from_numpy(va).cuda()].cpu().numpy()))
+    assert np.array_equal(model.predict(feats).cpu().numpy(), got)
     conf = classification.confusion_matrix(pred[torch.from_numpy(va).cuda()],
                                            torch.from_numpy(labels[va]).cuda(), n_classes=3)
     assert conf.sum() == len(va) and np.trace(conf) / conf.sum() > 0.9
@@ -594,3 +595,25 @@ def test_verbose_mode_prints_like_the_reference(capsys):
     text = capsys.readouterr().out
     assert text.count("this scale took") == 2 and "final rate of" in text
     assert "querying 3000 points against a search space of" in text
+
+
+def test_flexcloud_on_the_device():
+    # the container with device-resident assets, through the pipeline conveniences
+    from nimrud_amd.utils import point_clouds
+    pts, labels = synth.scene_cloud(30000, extent=10.0, n_poles=6, n_spheres=2, seed=171)
+    pts = pts + np.array([4.0e5, 5.1e6, 300.0])                      # UTM-like: the corner shift helps
+    cloud = point_clouds.FlexCloud(pts, device="cuda")
+    feats = cloud.add_multiscale_features([0.1, 0.2], [0.3, 0.6])
+    assert feats.is_cuda and feats.shape == (30000, 8)
+    assert cloud.assets["geometry_mso"]["meta"] == {"voxel": [0.1, 0.2], "scales": [0.3, 0.6]}
+    want = oracle.process_fast(pts - pts[0], pts - pts[0], [0.1, 0.2], [0.3, 0.6])
+    assert_features_close(feats.cpu().numpy(), want, pts - pts[0])
+    cloud.add_asset(labels[:20000], np.arange(20000), "known_label")
+    idx, block = cloud.intersection(["geometry_mso", "known_label"])
+    assert idx.is_cuda and block.shape == (20000, 9)
+    model, clf = classification.train_forest(block[:, :8], block[:, 8].to(torch.int64), n_estimators=8,
+                                             max_depth=8, n_jobs=4)
+    predicted = cloud.add_labels_from(model, "geometry_mso")
+    assert (predicted.cpu().numpy()[20000:] == labels[20000:]).mean() > 0.9
+    host = point_clouds.FlexCloud(pts)
+    assert np.array_equal(host.take(), pts + 0.0)
