@@ -75,9 +75,13 @@ def _worker(rank, world, port, points, parts, results):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_halo_exchange_matches_single_process():
-    points, _ = synth.scene_cloud(16000, extent=24.0, n_poles=12, n_spheres=4, seed=13)
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_matches_single_process(world):
+    # world 3 on a long strip: ranks 0 and 2 are not neighbours and exchange nothing
+    extent = 24.0 if world == 2 else 40.0
+    points, _ = synth.scene_cloud(16000, extent=extent, n_poles=12, n_spheres=4, seed=13)
+    if world == 3:
+        points = points[points[:, 1] < 8.0]
     parts = parallel.partition_tiles(points, world)
     assert sum(len(p) for p in parts) == len(points)
     manager = mp.Manager()
