@@ -581,6 +581,13 @@ __device__ __forceinline__ uint64_t nm_point_key(const double* __restrict__ p, c
     return nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
 }
 
+// both builders are chains of dependent memory round trips (coordinates / key -> hash probe -> atomic),
+// and a CU can hold only 2048 threads: with one group of 64 keys in flight per wave the kernels ran at
+// the latency of those chains.  so every wave works on NM_GROUPS independent groups of 64 keys at a
+// time: their loads, probes and atomics are issued together.
+constexpr int NM_GROUPS = 4;
+static_assert(INDEX_ITERS % NM_GROUPS == 0, "groups must tile the wave's iterations");
+
 // one pass over the coordinate stream: the keys are computed and stored for k_index_bits_any, and the
 // run heads go to the hash table.
 __global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restrict__ xyz, int64_t n,
@@ -597,37 +604,56 @@ __global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restr
     // superblock of the key just before this wave's first one
     uint64_t carry = ~0ull;
     if (wave_lo > 0 && wave_lo <= n) carry = nm_point_key(xyz + (wave_lo - 1) * 3, L) >> NM_LOCAL_BITS;
-    for (int it = 0; it < INDEX_ITERS; ++it) {
-        const int64_t i = wave_lo + it * 64 + lane;
-        if (wave_lo + it * 64 >= n) break;
-        const bool valid = i < n;
-        uint64_t k = 0ull;
-        if (valid) {
-            k = nm_point_key(xyz + i * 3, L);
-            key[i] = k;
+    for (int it = 0; it < INDEX_ITERS; it += NM_GROUPS) {
+        const int64_t base = wave_lo + (int64_t)it * 64;
+        if (base >= n) break;
+        uint64_t sb[NM_GROUPS];
+        bool head[NM_GROUPS];
+        uint32_t slot[NM_GROUPS];
+        uint64_t peek[NM_GROUPS];
+#pragma unroll
+        for (int g = 0; g < NM_GROUPS; ++g) {
+            const int64_t i = base + g * 64 + lane;
+            const bool valid = i < n;
+            uint64_t k = 0ull;
+            if (valid) {
+                k = nm_point_key(xyz + i * 3, L);
+                key[i] = k;
+            }
+            sb[g] = k >> NM_LOCAL_BITS;
+            uint64_t prev = __shfl_up(sb[g], 1);
+            if (lane == 0) prev = carry;
+            carry = __shfl(sb[g], 63);
+            head[g] = valid && sb[g] != prev;
         }
-        const uint64_t sb = k >> NM_LOCAL_BITS;
-        uint64_t prev = __shfl_up(sb, 1);
-        if (lane == 0) prev = carry;
-        carry = __shfl(sb, 63);
-        if (valid && sb != prev) {
-            uint32_t slot = nm_hash64(sb) & I.hash_mask;
+        // first probe of all groups at once
+#pragma unroll
+        for (int g = 0; g < NM_GROUPS; ++g) {
+            slot[g] = nm_hash64(sb[g]) & I.hash_mask;
+            peek[g] = head[g] ? I.hash[slot[g]].key : sb[g];
+        }
+#pragma unroll
+        for (int g = 0; g < NM_GROUPS; ++g) {
+            if (!head[g] || peek[g] == sb[g]) continue;      // already in the table
+            uint32_t sl = slot[g];
+            uint64_t pk = peek[g];
             for (;;) {
-                const uint64_t peek = I.hash[slot].key;
-                if (peek == sb) break;
-                if (peek != NM_HASH_EMPTY) {
-                    slot = (slot + 1) & I.hash_mask;
+                if (pk == sb[g]) break;
+                if (pk != NM_HASH_EMPTY) {
+                    sl = (sl + 1) & I.hash_mask;
+                    pk = I.hash[sl].key;
                     continue;
                 }
                 const unsigned long long seen =
-                    atomicCAS((unsigned long long*)&I.hash[slot].key,
-                              (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb);
+                    atomicCAS((unsigned long long*)&I.hash[sl].key,
+                              (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb[g]);
                 if (seen == NM_HASH_EMPTY) {
-                    won_slot[atomicAdd(&won_count, 1u)] = slot;
+                    won_slot[atomicAdd(&won_count, 1u)] = sl;
                     break;
                 }
-                if (seen == sb) break;
-                slot = (slot + 1) & I.hash_mask;
+                if (seen == sb[g]) break;
+                sl = (sl + 1) & I.hash_mask;
+                pk = I.hash[sl].key;
             }
         }
     }
@@ -654,34 +680,67 @@ __global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restri
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
-    for (int it = 0; it < INDEX_ITERS; ++it) {
-        const int64_t i = wave_lo + it * 64 + lane;
-        if (wave_lo + it * 64 >= n) break;
-        const bool valid = i < n;
-        const uint64_t k = valid ? key[i] : 0ull;
-        const uint64_t prev = __shfl_up(k, 1);
-        // runs are delimited inside this group of 64 only: lane 0 always starts one
-        const bool row_head = lane == 0 || (k >> NM_SBX_BITS) != (prev >> NM_SBX_BITS) || !valid;
-        const bool sb_head = lane == 0 || (k >> NM_LOCAL_BITS) != (prev >> NM_LOCAL_BITS) || !valid;
-        const unsigned long long below = (2ull << lane) - 1ull;
-        const unsigned long long sbm = __ballot(sb_head);
-        int32_t leaf = -1;
-        if (sb_head && valid) leaf = nm_hash_find(I, k >> NM_LOCAL_BITS);
-        leaf = __shfl(leaf, 63 - __clzll((long long)(sbm & below)));
-        const unsigned long long rowm = __ballot(row_head);
-        const int seg_start = 63 - __clzll((long long)(rowm & below));
-        uint32_t bits = valid ? (1u << ((uint32_t)k & 31u)) : 0u;
+    const unsigned long long below = (2ull << lane) - 1ull;
+    for (int it = 0; it < INDEX_ITERS; it += NM_GROUPS) {
+        const int64_t base = wave_lo + (int64_t)it * 64;
+        if (base >= n) break;
+        uint64_t k[NM_GROUPS];
+        bool valid[NM_GROUPS], row_head[NM_GROUPS], sb_head[NM_GROUPS];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t other = __shfl_up(bits, off);
-            if (lane - off >= seg_start) bits |= other;
+        for (int g = 0; g < NM_GROUPS; ++g) {
+            const int64_t i = base + g * 64 + lane;
+            valid[g] = i < n;
+            k[g] = valid[g] ? key[i] : 0ull;
         }
-        const bool tail = valid && (lane == 63 || ((rowm >> (lane + 1)) & 1ull) || i + 1 >= n);
-        if (tail && leaf >= 0) {
-            const uint32_t local = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
-            // no return value wanted: the wave does not wait for the atomic.  M is counted afterwards
-            // from the leaves (k_count_voxels)
-            atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)], bits);
+        uint32_t slot[NM_GROUPS];
+        uint4 entry[NM_GROUPS];
+#pragma unroll
+        for (int g = 0; g < NM_GROUPS; ++g) {
+            const uint64_t prev = __shfl_up(k[g], 1);
+            // runs are delimited inside one group of 64 only: lane 0 always starts one
+            row_head[g] = lane == 0 || (k[g] >> NM_SBX_BITS) != (prev >> NM_SBX_BITS) || !valid[g];
+            sb_head[g] = lane == 0 || (k[g] >> NM_LOCAL_BITS) != (prev >> NM_LOCAL_BITS) || !valid[g];
+            // first probe of every group's run heads, all in flight together
+            slot[g] = nm_hash64(k[g] >> NM_LOCAL_BITS) & I.hash_mask;
+            entry[g] = make_uint4(0u, 0u, 0u, 0u);
+            if (sb_head[g] && valid[g]) entry[g] = *(const uint4*)&I.hash[slot[g]];
+        }
+#pragma unroll
+        for (int g = 0; g < NM_GROUPS; ++g) {
+            int32_t leaf = -1;
+            if (sb_head[g] && valid[g]) {
+                const uint64_t want = k[g] >> NM_LOCAL_BITS;
+                uint4 e = entry[g];
+                uint32_t sl = slot[g];
+                for (;;) {
+                    const uint64_t have = (uint64_t)e.x | ((uint64_t)e.y << 32);
+                    if (have == want) {
+                        leaf = (int32_t)e.z;
+                        break;
+                    }
+                    if (have == NM_HASH_EMPTY) break;
+                    sl = (sl + 1) & I.hash_mask;
+                    e = *(const uint4*)&I.hash[sl];
+                }
+            }
+            const unsigned long long sbm = __ballot(sb_head[g]);
+            leaf = __shfl(leaf, 63 - __clzll((long long)(sbm & below)));
+            const unsigned long long rowm = __ballot(row_head[g]);
+            const int seg_start = 63 - __clzll((long long)(rowm & below));
+            uint32_t bits = valid[g] ? (1u << ((uint32_t)k[g] & 31u)) : 0u;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t other = __shfl_up(bits, off);
+                if (lane - off >= seg_start) bits |= other;
+            }
+            const int64_t i = base + g * 64 + lane;
+            const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull) || i + 1 >= n);
+            if (tail && leaf >= 0) {
+                const uint32_t local = (uint32_t)k[g] & ((1u << NM_LOCAL_BITS) - 1u);
+                // no return value wanted: the wave does not wait for the atomic.  M is counted
+                // afterwards from the leaves (k_count_voxels)
+                atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)], bits);
+            }
         }
     }
 }
