@@ -675,9 +675,23 @@ __global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restr
     }
 }
 
+// the stream is in Z-order, so consecutive keys rarely share a row word and almost every key would cost
+// a global atomic.  a block's 4096 keys are a compact patch of space, though: they touch far fewer row
+// words than there are keys.  so the block first ORs its bits into a small table in LDS (LDS atomics
+// are local to the CU) and then sends one global atomic per distinct row word.
+constexpr int BITS_TABLE = 4096;              // LDS slots (word index + bits): 32 KB per block
+constexpr uint32_t BITS_EMPTY = 0xFFFFFFFFu;
+
 __global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restrict__ key, int64_t n,
                                                         IndexDev I)
 {
+    __shared__ uint32_t t_word[BITS_TABLE];
+    __shared__ uint32_t t_bits[BITS_TABLE];
+    for (int t = threadIdx.x; t < BITS_TABLE; t += blockDim.x) {
+        t_word[t] = BITS_EMPTY;
+        t_bits[t] = 0u;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
     const unsigned long long below = (2ull << lane) - 1ull;
@@ -737,11 +751,30 @@ __global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restri
             const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull) || i + 1 >= n);
             if (tail && leaf >= 0) {
                 const uint32_t local = (uint32_t)k[g] & ((1u << NM_LOCAL_BITS) - 1u);
+                const uint32_t word = (uint32_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS);
+                // into the block's table; a few probes, then straight to memory if the table is crowded
+                uint32_t ts = (word * 0x9E3779B1u) >> (32 - 12);
+                bool stored = false;
+#pragma unroll 1
+                for (int probe = 0; probe < 8; ++probe) {
+                    const uint32_t seen = atomicCAS(&t_word[ts], BITS_EMPTY, word);
+                    if (seen == BITS_EMPTY || seen == word) {
+                        atomicOr(&t_bits[ts], bits);
+                        stored = true;
+                        break;
+                    }
+                    ts = (ts + 1) & (BITS_TABLE - 1);
+                }
                 // no return value wanted: the wave does not wait for the atomic.  M is counted
                 // afterwards from the leaves (k_count_voxels)
-                atomicOr(&I.leaf[(size_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS)], bits);
+                if (!stored) atomicOr(&I.leaf[word], bits);
             }
         }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < BITS_TABLE; t += blockDim.x) {
+        const uint32_t word = t_word[t];
+        if (word != BITS_EMPTY) atomicOr(&I.leaf[word], t_bits[t]);
     }
 }
 
