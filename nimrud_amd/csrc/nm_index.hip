@@ -815,11 +815,29 @@ __device__ __forceinline__ uint64_t nm_spread3(uint32_t v)
     return x;
 }
 
+// 2-way Morton spread of up to 21 bits
+__device__ __forceinline__ uint64_t nm_spread2(uint32_t v)
+{
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+// how the three axes share the compact Z-order key (see k_order_keys)
+struct ZLayout {
+    int32_t w1, w2;        // smallest and middle width (after NM_ORDER_DROP)
+    int32_t off2[3];       // slot of an axis in the 2-way zone, -1 for the axis with the smallest width
+};
+
 constexpr int NM_ORDER_DROP = 0;   // measured: dropping 2 bits per axis saves a radix pass but costs more in the index build and the fused kernel
 
 __global__ __launch_bounds__(256) void k_order_keys(const double* __restrict__ xyz, int64_t n,
                                                     int64_t stride, LatticeDev L, int morton,
-                                                    uint64_t* __restrict__ key,
+                                                    ZLayout Z, uint64_t* __restrict__ key,
                                                     uint32_t* __restrict__ val)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -836,17 +854,21 @@ __global__ __launch_bounds__(256) void k_order_keys(const double* __restrict__ x
     uint64_t k;
     if (morton) {
         // Z-order with the always-zero bits squeezed out: bit b of every axis that HAS a bit b, lowest
-        // bits first.  same order as the plain 3-way interleave, but only wx+wy+wz key bits to sort
-        // (one radix pass fewer when the axes have different widths)
-        const uint32_t ux = (uint32_t)cx >> NM_ORDER_DROP, uy = (uint32_t)cy >> NM_ORDER_DROP,
-                       uz = (uint32_t)cz >> NM_ORDER_DROP;
-        const int bx = L.wx - NM_ORDER_DROP, by = L.wy - NM_ORDER_DROP, bz = L.wz - NM_ORDER_DROP;
+        // bits first - same order as the plain 3-way interleave, but only wx+wy+wz key bits to sort.
+        // with w1 <= w2 the two smaller widths: bits below w1 are interleaved 3-way, bits in [w1, w2)
+        // 2-way among the axes that still have bits, the rest belongs to the widest axis alone.
+        const uint32_t c[3] = {(uint32_t)cx >> NM_ORDER_DROP, (uint32_t)cy >> NM_ORDER_DROP,
+                               (uint32_t)cz >> NM_ORDER_DROP};
         k = 0ull;
-        int pos = 0;
-        for (int b = 0; b < 21; ++b) {
-            if (b < bx) k |= (uint64_t)((ux >> b) & 1u) << pos++;
-            if (b < by) k |= (uint64_t)((uy >> b) & 1u) << pos++;
-            if (b < bz) k |= (uint64_t)((uz >> b) & 1u) << pos++;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t lo = c[a] & ((1u << Z.w1) - 1u);
+            k |= nm_spread3(lo) << a;
+            if (Z.off2[a] >= 0) {
+                const uint32_t mid = (c[a] >> Z.w1) & ((1u << (Z.w2 - Z.w1)) - 1u);
+                k |= nm_spread2(mid) << (3 * Z.w1 + Z.off2[a]);
+                k |= (uint64_t)(c[a] >> Z.w2) << (3 * Z.w1 + 2 * (Z.w2 - Z.w1));
+            }
         }
     } else {
         k = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
@@ -866,7 +888,25 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
     for (int w : {L.wx, L.wy, L.wz}) sort_bits += w > NM_ORDER_DROP ? w - NM_ORDER_DROP : 0;
     if (sort_bits < 1) sort_bits = 1;
     const unsigned bits = morton ? (unsigned)sort_bits : (unsigned)L.keybits;
-    k_order_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, morton, key_tmp,
+    // axis roles in the compact Z-order key: the axis with the smallest width drops out of the 2-way
+    // zone; with ties the later axis is treated as the smaller one (it then simply has no bits there)
+    int wd[3] = {L.wx - NM_ORDER_DROP, L.wy - NM_ORDER_DROP, L.wz - NM_ORDER_DROP};
+    for (int a = 0; a < 3; ++a) wd[a] = wd[a] > 0 ? wd[a] : 0;
+    int smallest = 0;
+    for (int a = 1; a < 3; ++a)
+        if (wd[a] <= wd[smallest]) smallest = a;
+    ZLayout Z;
+    Z.w1 = wd[smallest];
+    Z.w2 = 64;
+    for (int a = 0, slot2 = 0; a < 3; ++a) {
+        if (a == smallest) {
+            Z.off2[a] = -1;
+        } else {
+            Z.off2[a] = slot2++;
+            if (wd[a] < Z.w2) Z.w2 = wd[a];
+        }
+    }
+    k_order_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, morton, Z, key_tmp,
                                                        val_tmp);
     NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp,
                                           order, (size_t)n, 0, bits, s));
