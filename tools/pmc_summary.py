@@ -4,8 +4,8 @@ and per-launch HBM traffic of the dominant kernel from separate --pmc FETCH_SIZE
 
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced
 streaming read; WRITE_SIZE is exact; both are in KiB.  calibrated on our own access pattern in the same
-runs: k_cell_keys_only / k_bounds read exactly 24 B per point with 8-byte loads at a 24-byte stride and
-report 12 B per point; k_cell_keys_only writes exactly 8 B per point and reports 8.
+runs: k_bounds reads exactly 24 B per point with 8-byte loads at a 24-byte stride and reports 12 B per
+point; the key kernels write exactly 8 (or 12) B per point and report exactly that.
 
 usage: python tools/pmc_summary.py <trace_dir> <fetch_dir> <write_dir> <sq_dir...> <tag>
 """
