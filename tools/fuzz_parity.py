@@ -56,16 +56,23 @@ for case in range(n_cases):
         lat_ok = False
     if not lat_ok:
         continue
-    want = oracle.process_fast(q, pts, edges, radii)
+    knn = int(rs.choice([0, 0, 4, 8, 12])) if kind != 3 else 0     # lattice ties make kNN sets ambiguous
+    factor = float(rs.uniform(1.5, 4.0))
+    if knn:
+        want = np.concatenate([oracle.one_scale_knn(q, pts, e, r, knn, radius_factor=factor)
+                               for e, r in zip(edges, radii)], axis=1)
+    else:
+        want = oracle.process_fast(q, pts, edges, radii)
     dq = torch.from_numpy(np.ascontiguousarray(q)).cuda()
     dp = dq if not separate else torch.from_numpy(np.ascontiguousarray(pts)).cuda()
     per_scale = bool(rs.rand() < 0.3)
-    got = multiscale.process_gpu(dq, dp, edges, radii, per_scale=per_scale).cpu().numpy()
+    got = multiscale.process_gpu(dq, dp, edges, radii, per_scale=per_scale, knn_min=knn,
+                                 knn_radius_factor=factor).cpu().numpy()
     try:
         assert_features_close(got, want, np.concatenate((pts, q[np.abs(q).max(1) < 1e6])))
     except AssertionError as err:
-        print("CASE %d FAILED kind=%d n=%d edges=%s radii=%s separate=%s per_scale=%s: %s"
-              % (case, kind, n, edges, radii, separate, per_scale, str(err)[:200]), flush=True)
+        print("CASE %d FAILED kind=%d n=%d edges=%s radii=%s separate=%s per_scale=%s knn=%d factor=%.3f: %s"
+              % (case, kind, n, edges, radii, separate, per_scale, knn, factor, str(err)[:200]), flush=True)
         np.savez("gpurun_out/fuzz_fail_%d.npz" % case, pts=pts, q=q, edges=edges, radii=radii)
         continue
     eig = np.abs(got - want)[:, [c for s in range(n_scales) for c in (4 * s + 2, 4 * s + 3)]]
