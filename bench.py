@@ -112,6 +112,21 @@ def cpu_baseline_multicore(points, edges, radii, sample, workers):
                                       % (len(tile), len(tasks), workers, dt)}
 
 
+def cpu_lattice_c(points, edges, radii, sample):
+    """a stronger CPU point than the reference's structure: the oracle's plain-C restatement (hash set of
+    occupied voxels, lattice enumeration, OpenMP over queries) on a larger slice of the same cloud."""
+    from oracle import nimrud_oracle as oracle
+    threads = min(16, os.cpu_count() or 1)
+    lo = max(0, len(points) // 2 - sample // 2)
+    tile = np.ascontiguousarray(points[lo:lo + sample])
+    t0 = time.perf_counter()
+    oracle.process_c(tile, tile, edges, radii, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": len(tile) * len(edges) / dt, "unit": "point-scales/s", "cores": threads,
+            "kind": "port", "sample": "oracle/lattice_oracle.c (gcc -O2 -fopenmp) on a %d-point slice, "
+                                      "%d scales, %.1f s" % (len(tile), len(edges), dt)}
+
+
 def main():
     args = parse_args()
     import torch
@@ -264,6 +279,10 @@ def main():
                         points, edges, radii, args.cpu_sample, workers)
                 except Exception as err:   # noqa: BLE001 - a reported extra, never fatal
                     record["cpu_baseline_multicore"] = {"error": str(err)[:200]}
+            try:
+                record["cpu_lattice_c"] = cpu_lattice_c(points, edges, radii, 2_000_000)
+            except Exception as err:       # noqa: BLE001
+                record["cpu_lattice_c"] = {"error": str(err)[:200]}
         else:
             record["cpu_baseline"] = None
         print(json.dumps(record))

@@ -302,6 +302,57 @@ def one_scale_knn(query_cloud, search_cloud, edge_length, radius, k_min, radius_
 
 
 # --------------------------------------------------------------------------------------------------
+# the plain-C restatement (oracle/lattice_oracle.c): all rows of full-size configurations in seconds
+# --------------------------------------------------------------------------------------------------
+
+_C_ORACLE = None
+
+
+def _c_oracle():
+    global _C_ORACLE
+    if _C_ORACLE is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblattice_oracle.so")
+        if not os.path.exists(path):
+            raise ImportError("oracle/liblattice_oracle.so is not built: make -C oracle")
+        lib = ctypes.CDLL(path)
+        lib.nm_oracle_scale.restype = ctypes.c_long
+        lib.nm_oracle_scale.argtypes = [
+            ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_void_p, ctypes.c_long,
+            ctypes.c_long, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
+            ctypes.c_void_p, ctypes.c_int]
+        _C_ORACLE = lib
+    return _C_ORACLE
+
+
+def one_scale_c(query_cloud, search_cloud, edge_length, radius, threads=0, bounds=None,
+                return_voxel_count=False):
+    """one scale through oracle/lattice_oracle.c: gathers the real voxel centres of every neighborhood
+    and computes mean / ddof=1 covariance / Jacobi eigenvalues in fp64 (no kd-tree, no numpy.cov, no
+    LAPACK, no integer moments).  threads = 0 uses all cores OpenMP sees."""
+    query = np.ascontiguousarray(np.asarray(query_cloud, dtype=np.float64))
+    search = np.ascontiguousarray(np.asarray(search_cloud, dtype=np.float64))
+    lattice = Lattice(search[:, :3], edge_length, bounds=bounds)
+    mc = np.ascontiguousarray(lattice.minimum_corner, dtype=np.float64)
+    widths = np.ascontiguousarray(lattice.widths, dtype=np.int32)
+    out = np.zeros((query.shape[0], 4))
+    m = _c_oracle().nm_oracle_scale(
+        query.ctypes.data, query.shape[0], query.shape[1], search.ctypes.data, search.shape[0],
+        search.shape[1], mc.ctypes.data, float(edge_length), widths.ctypes.data, float(radius),
+        out.ctypes.data, int(threads))
+    if m < 0:
+        raise MemoryError("lattice_oracle: allocation failed")
+    return (out, int(m)) if return_voxel_count else out
+
+
+def process_c(query_cloud, search_cloud, edge_lengths, radii, threads=0, bounds=None):
+    assert len(edge_lengths) == len(radii)
+    return np.concatenate([one_scale_c(query_cloud, search_cloud, e, r, threads=threads, bounds=bounds)
+                           for e, r in zip(edge_lengths, radii)], axis=1)
+
+
+# --------------------------------------------------------------------------------------------------
 # classifier slot: random forest evaluation
 # --------------------------------------------------------------------------------------------------
 

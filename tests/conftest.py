@@ -14,6 +14,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # the C restatement of the oracle is test infrastructure: build it if it is not there yet
+    import subprocess
+    if not os.path.exists(os.path.join(REPO, "oracle", "liblattice_oracle.so")):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=False)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -277,6 +277,8 @@ def test_config2_full_size_properties():
     rows = sub.cpu().numpy()
     want = oracle.process_fast(pts[rows], pts, edges, radii)
     assert_features_close(f[rows], want, pts)
+    # (e) ALL rows against the plain-C oracle (real voxel centres, two-pass covariance, Jacobi)
+    assert_features_close(f, oracle.process_c(pts, pts, edges, radii), pts)
 
 
 # ---- multi-GPU path pieces on one GPU ---------------------------------------------------------------
@@ -532,6 +534,11 @@ def test_config3_full_size_properties():
     assert len(rows) > 5000
     want = oracle.process_fast(pts[rows], pts[outer], edges, radii, bounds=(lo, hi))
     assert_features_close(f[rows], want, pts)
+    # every one of the 5e7 point-scales against the plain-C oracle: populations bit-exact, features
+    # within the contract
+    for s, (e, r) in enumerate(zip(edges, radii)):
+        want_s = oracle.one_scale_c(pts, pts, e, r)
+        assert_features_close(f[:, 4 * s:4 * s + 4], want_s, pts)
 
 
 def test_config4_lidar_power_law_with_knn_fallback():
