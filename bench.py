@@ -262,6 +262,9 @@ def main():
                 "traffic_source": "profiles/r1_final_traffic.json (rocprofv3 --pmc, separate passes)",
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms_avg": k_ms,
+                "note": "nominal bound is HBM, the measured one is vector-ALU issue: SQ_ACTIVE_INST_VALU "
+                        "covers the kernel's whole duration on every SIMD (profiles/r1_final_traffic.json); "
+                        "PMC traffic is 1.09x the algorithmic bytes, nothing is re-read from HBM",
             },
             "stage_ms_per_step": {
                 "cell_keys_and_sort": ms[0] / args.steps,

@@ -36,8 +36,6 @@ extern "C" int nm_set_overlap(nm_ctx* ctx, int enabled)
 {
     if (!ctx) return NM_ERR_INVALID;
     ctx->overlap = enabled != 0;
-    // values above 1 also set how many fused-kernel workgroups per SIMD run beside a build (tuning)
-    if (enabled >= 2 && enabled <= 8) ctx->ladder_waves = enabled;
     return NM_OK;
 }
 

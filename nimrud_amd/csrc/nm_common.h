@@ -20,7 +20,6 @@ struct nm_ctx {
     // whole-ladder pipelining: the index of scale i+1 is built on `aux` while the fused kernel of
     // scale i runs on the caller's stream (nm_set_overlap)
     bool overlap = false;        // measured: the long kernel starves the build stream; no gain yet
-    int ladder_waves = 5;        // fused-kernel workgroups per SIMD while a build runs beside it
     hipStream_t aux = nullptr;
     std::vector<hipEvent_t> sync_events;
     // k-nearest-voxel fallback for sparse neighborhoods (nm_set_knn_fallback); 0 = off

@@ -912,14 +912,12 @@ static int candidate_width(double radius, double edge, int32_t* dmin)
 
 // picks the kernel instance for (W, r/e) and launches it
 static void launch_scale_kernel(const ScaleArgs& A, const nm_lattice* lat, double radius, int W,
-                                hipStream_t s, int num_cus, int waves_per_simd)
+                                hipStream_t s)
 {
     // one workgroup per 64-query batch: the hardware dispatcher balances the uneven batches (waves
     // that need several passes) better than a persistent grid did (measured: persistent -17 %)
     const int blocks = (int)((A.n_slots + 63) / 64);
     const int generic_blocks = blocks;
-    (void)num_cus;
-    (void)waves_per_simd;
     // static pruning of the candidate window is sound only while the rounding of cells and centres
     // stays far below the 1e-4-cell padding of the bounds: 16 ulp of the largest coordinate the
     // lattice can produce must be smaller than that.
@@ -1077,7 +1075,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.feat = d_feat;
         A.fstride = feat_stride;
         A.stats = I.counters + 8;
-        launch_scale_kernel(A, lat, radius, W, s, ctx->num_cus, 6);
+        launch_scale_kernel(A, lat, radius, W, s);
         launch_knn_fallback(ctx, A, radius, s);
     }
     nm_profile_mark(ctx, s);
@@ -1278,7 +1276,7 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
             A.feat = d_feat + 4 * i;
             A.fstride = feat_stride;
             A.stats = I.counters + 8;
-            launch_scale_kernel(A, &lats[i], radii[i], W, s, ctx->num_cus, overlap ? ctx->ladder_waves : 6);
+            launch_scale_kernel(A, &lats[i], radii[i], W, s);
             launch_knn_fallback(ctx, A, radii[i], s);
         }
         nm_profile_mark(ctx, s);
