@@ -595,9 +595,12 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
             for (int r = 0; r < MASK_REGS; ++r) asm volatile("" : "+v"(inside[r]));
 #pragma unroll
             for (int j = 0; j < W; ++j) {
+                // rows of the reflected window that can never hold a neighbor are skipped at compile time
+                // for r = 3e (14 of the 49); with the run-time table they simply look up an empty mask
                 uint32_t valid[W];
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
+                    if (RHO3 && NM_BOUNDS_RHO3.rb[j * W + k].b < 0) continue;
                     const uint64_t row = rows[rhome + (k - C) * step_z + (j - C) * step_y];
                     const int r = j * W + k;
                     const uint32_t in =
@@ -606,6 +609,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                 }
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
+                    if (RHO3 && NM_BOUNDS_RHO3.rb[j * W + k].b < 0) continue;
                     const uint32_t t = lut[valid[k]];
                     aj[j] += t;
                     bk[k] += t;
