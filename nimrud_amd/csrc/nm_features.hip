@@ -26,6 +26,7 @@
 constexpr int ROWS_CAP = 512;   // staged (y,z) rows per wave, 8 B each
 constexpr int SBT_CAP = 192;    // superblock slots of the staged box (3 in x)
 constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anchor lane
+constexpr int NM_BOX_EX = 62;   // x extent of a staged box: 64-bit rows, kept shifted left by two
 
 struct ScaleArgs {
     const double* query;
@@ -159,6 +160,9 @@ __device__ __forceinline__ double nm_rsqrt_fast(double x)
     return y * (1.5 - 0.5 * x * y * y);
 }
 
+#ifndef NM_CUBIC_NEWTON_STEPS
+#define NM_CUBIC_NEWTON_STEPS 5   // quadratic from x0 = 2: error 0.27, 6e-2, 3e-3, 1e-5, 9e-11, < 1e-17
+#endif
 __device__ __forceinline__ void nm_eig3_fast(double a00, double a01, double a02, double a11,
                                              double a12, double a22, double& l0, double& l1,
                                              double& l2)
@@ -183,11 +187,28 @@ __device__ __forceinline__ void nm_eig3_fast(double a00, double a01, double a02,
     const double ra = fabs(r);
     double x = 2.0;
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
+    for (int it = 0; it < NM_CUBIC_NEWTON_STEPS; ++it) {
         const double x2 = x * x;
         const double f = x * (x2 - 3.0) - 2.0 * ra;
         const double fp = 3.0 * x2 - 3.0;
         x = x - f * __builtin_amdgcn_rcp(fp);
+    }
+    // the other two roots of x^3 - 3x - 2r are -x/2 +- sqrt(3 (1 - x^2/4)).  with t = 1 - x^2/4
+    // formed as (2-x)(2+x)/4 (the difference is exact) an error d in x becomes d / (2 sqrt t) in the
+    // pair, so whenever the pair is not nearly double (t >= 1e-6: error < 1e-13) the closed form is as
+    // good as the deflation below and a third of its cost.  nearly all neighborhoods take it; a wave
+    // runs the deflation only when one of its lanes has a (near-)double pair.
+    const double t = (2.0 - x) * (2.0 + x) * 0.25;
+    if (__builtin_expect(t >= 1e-6, 1)) {
+        const double t3 = 3.0 * t;
+        const double s3 = t3 * nm_rsqrt_fast(t3);
+        const double h = 0.5 * x;
+        const double f0 = top ? x : h + s3;
+        const double f1 = top ? s3 - h : h - s3;
+        l0 = q + p * f0;
+        l1 = q + p * f1;
+        l2 = 3.0 * q - l0 - l1;
+        return;
     }
     const double sx = top ? x : -x;
     const double lam = q + p * sx;
@@ -296,6 +317,39 @@ __device__ __forceinline__ int32_t wave_reduce_i32(int32_t v)
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v) { return wave_reduce_i32<true>(v); }
 __device__ __forceinline__ int32_t wave_max_i32(int32_t v) { return wave_reduce_i32<false>(v); }
 
+// the bounding box of the pending lanes needs three minima and three maxima per pass.  written through
+// update_dpp each step costs three instructions (two copies and the min); as DPP-modified v_min / v_max
+// it is one.  the six chains are interleaved, so a value is next read five instructions after it was
+// written (the DPP read-after-write hazard needs two wait states), and the leading s_nop covers the
+// instruction that produced the inputs and any preceding write of EXEC.
+__device__ __forceinline__ void wave_bbox(int32_t& lox, int32_t& hix, int32_t& loy, int32_t& hiy,
+                                          int32_t& loz, int32_t& hiz)
+{
+#define NM_SIX(ctrl)                                        \
+    "v_min_i32_dpp %0, %0, %0 " ctrl "\n"                   \
+    "v_max_i32_dpp %1, %1, %1 " ctrl "\n"                   \
+    "v_min_i32_dpp %2, %2, %2 " ctrl "\n"                   \
+    "v_max_i32_dpp %3, %3, %3 " ctrl "\n"                   \
+    "v_min_i32_dpp %4, %4, %4 " ctrl "\n"                   \
+    "v_max_i32_dpp %5, %5, %5 " ctrl "\n"
+    asm volatile("s_nop 4\n"
+                 NM_SIX("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 NM_SIX("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 NM_SIX("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 NM_SIX("row_mirror row_mask:0xf bank_mask:0xf")
+                 NM_SIX("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 NM_SIX("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1\n"
+                 : "+v"(lox), "+v"(hix), "+v"(loy), "+v"(hiy), "+v"(loz), "+v"(hiz));
+#undef NM_SIX
+    lox = __builtin_amdgcn_readlane(lox, 63);
+    hix = __builtin_amdgcn_readlane(hix, 63);
+    loy = __builtin_amdgcn_readlane(loy, 63);
+    hiy = __builtin_amdgcn_readlane(hiy, 63);
+    loz = __builtin_amdgcn_readlane(loz, 63);
+    hiz = __builtin_amdgcn_readlane(hiz, 63);
+}
+
 __device__ __forceinline__ void lds_fence()
 {
     // one wave per workgroup: LDS operations of a wave complete in order, the compiler must not
@@ -387,13 +441,36 @@ constexpr RowBoundTable nm_make_bounds(double rho2, bool prune)
 constexpr RowBoundTable NM_BOUNDS_RHO3 = nm_make_bounds<7>(9.0, true);
 
 // packed LUT fields: bits [0,8) count, [8,20) sum of bit index, [20,32) sum of index^2
+template <int W>
+struct MomentLut {
+    uint32_t v[1 << W];
+};
+template <int W>
+constexpr MomentLut<W> nm_make_lut()
+{
+    MomentLut<W> t{};
+    for (int m = 0; m < (1 << W); ++m) {
+        uint32_t n = 0, s1 = 0, s2 = 0;
+        for (int i = 0; i < W; ++i)
+            if (m & (1 << i)) {
+                n += 1;
+                s1 += i;
+                s2 += i * i;
+            }
+        t.v[m] = n | (s1 << 8) | (s2 << 20);
+    }
+    return t;
+}
+template <int W>
+__device__ const MomentLut<W> NM_LUT = nm_make_lut<W>();
+
 template <int W, bool RHO3>
 __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTable RT)
 {
     static_assert(W >= 3 && W <= 9 && (W & 1), "LUT kernel covers W = 3,5,7,9");
     static_assert(!RHO3 || W == 7, "the compile-time table is for W = 7");
     constexpr int C = (W - 1) / 2;
-    constexpr int ROWS_PER_REG = 32 / W;                          // packed mask fields per VGPR
+    constexpr int ROWS_PER_REG = 30 / W;                          // packed mask fields per VGPR, from bit 2
     constexpr int MASK_REGS = (W * W + ROWS_PER_REG - 1) / ROWS_PER_REG;
     __shared__ uint64_t rows[ROWS_CAP];
     __shared__ int32_t sbt[SBT_CAP];
@@ -404,17 +481,6 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
     const int32_t dmin = A.dmin;
     const int32_t dmax = dmin + W - 1;
 
-    for (int m = lane; m < (1 << W); m += 64) {
-        uint32_t n = 0, s1 = 0, s2 = 0;
-#pragma unroll
-        for (int i = 0; i < W; ++i)
-            if (m & (1 << i)) {
-                n += 1;
-                s1 += i;
-                s2 += i * i;
-            }
-        lut[m] = n | (s1 << 8) | (s2 << 20);
-    }
 
     const int64_t batch = nm_xcd_batch(blockIdx.x, gridDim.x);
     const int64_t slot = batch * 64 + lane;
@@ -496,13 +562,15 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                 }
                 constexpr uint32_t FULL = (1u << W) - 1u;
                 const int row = j * W + k;
-                inside[row / ROWS_PER_REG] |= ((~outside) & FULL) << ((row % ROWS_PER_REG) * W);
+                inside[row / ROWS_PER_REG] |= ((~outside) & FULL) << ((row % ROWS_PER_REG) * W + 2);
             }
             // keep the rows of different j apart: without this the scheduler interleaves all W*W
             // chains and the live set (W*W partial sums) costs two waves of occupancy
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // the moment table comes from constant data (computing it cost every wave ~70 vector instructions)
+    for (int m = lane; m < (1 << W); m += 64) lut[m] = NM_LUT<W>.v[m];
     lds_fence();
 
     uint32_t m_n = 0, m_sx = 0, m_sy = 0, m_sz = 0, m_sxx = 0, m_sxy = 0, m_sxz = 0, m_syy = 0,
@@ -514,14 +582,15 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         ++passes;
         // ---- choose the box: bounding box of the pending lanes if it fits, else a fixed box around
         //      the first pending lane
-        int32_t lox = wave_min_i32(done ? INT32_MAX : hx), hix = wave_max_i32(done ? INT32_MIN : hx);
-        int32_t loy = wave_min_i32(done ? INT32_MAX : hy), hiy = wave_max_i32(done ? INT32_MIN : hy);
-        int32_t loz = wave_min_i32(done ? INT32_MAX : hz), hiz = wave_max_i32(done ? INT32_MIN : hz);
+        int32_t lox = done ? INT32_MAX : hx, hix = done ? INT32_MIN : hx;
+        int32_t loy = done ? INT32_MAX : hy, hiy = done ? INT32_MIN : hy;
+        int32_t loz = done ? INT32_MAX : hz, hiz = done ? INT32_MIN : hz;
+        wave_bbox(lox, hix, loy, hiy, loz, hiz);
         int64_t ex64 = (int64_t)hix - lox + W, ey64 = (int64_t)hiy - loy + W,
                 ez64 = (int64_t)hiz - loz + W;
         int32_t ox = lox + dmin, oy = loy + dmin, oz = loz + dmin;
         int32_t ey = (int32_t)ey64, ez = (int32_t)ez64;
-        bool fits = ex64 <= 64 && ey64 <= ROWS_CAP && ez64 <= ROWS_CAP && ey64 * ez64 <= ROWS_CAP;
+        bool fits = ex64 <= NM_BOX_EX && ey64 <= ROWS_CAP && ez64 <= ROWS_CAP && ey64 * ez64 <= ROWS_CAP;
         if (fits) {
             int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - (oy >> NM_SBY_BITS) + 1;
             int32_t nsz = ((oz + ez - 1) >> NM_SBZ_BITS) - (oz >> NM_SBZ_BITS) + 1;
@@ -530,18 +599,20 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         if (!fits) {
             const int anchor = __ffsll((long long)todo) - 1;
             const int32_t ax = __shfl(hx, anchor), ay = __shfl(hy, anchor), az = __shfl(hz, anchor);
-            ox = ax + dmin - (64 - W) / 2;
+            ox = ax + dmin - (NM_BOX_EX - W) / 2;
             oy = ay + dmin - (ANCHOR_EYZ - W) / 2;
             oz = az + dmin - (ANCHOR_EYZ - W) / 2;
             ey = ANCHOR_EYZ;
             ez = ANCHOR_EYZ;
         }
-        const bool sel = !done && hx + dmin >= ox && hx + dmax < ox + 64 && hy + dmin >= oy &&
+        const bool sel = !done && hx + dmin >= ox && hx + dmax < ox + NM_BOX_EX && hy + dmin >= oy &&
                          hy + dmax < oy + ey && hz + dmin >= oz && hz + dmax < oz + ez;
 
         // ---- stage: leaf numbers of the box's superblocks (integer divisions by wave-uniform small
         //      numbers are done with a 20-bit reciprocal: exact for operands below 2^10)
-        const int32_t sbx0 = ox >> NM_SBX_BITS, sby0 = oy >> NM_SBY_BITS, sbz0 = oz >> NM_SBZ_BITS;
+        // the staged 64-bit rows start two cells before the box: bit b of a row is cell ox - 2 + b, so a
+        // lane's shifted row already is (occupancy << 2), a byte offset into the table
+        const int32_t sbx0 = (ox - 2) >> NM_SBX_BITS, sby0 = oy >> NM_SBY_BITS, sbz0 = oz >> NM_SBZ_BITS;
         const int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - sby0 + 1;
         const int32_t nsz = ((oz + ez - 1) >> NM_SBZ_BITS) - sbz0 + 1;
         const int32_t nsb = 3 * nsy * nsz;
@@ -562,7 +633,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         lds_fence();
         // ---- stage: 64-bit x-rows of the box, funnel-shifted out of the 32-bit leaf words
         const int32_t nrows = ey * ez;
-        const uint32_t sh = (uint32_t)(ox & 31);
+        const uint32_t sh = (uint32_t)((ox - 2) & 31);
 #pragma nounroll
         for (int32_t rr = lane; rr < nrows; rr += 64) {
             const int32_t rz = (int32_t)(((uint32_t)rr * inv_ey) >> 20);   // rr / ey (rr < 512)
@@ -603,14 +674,14 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                     if (RHO3 && NM_BOUNDS_RHO3.rb[j * W + k].b < 0) continue;
                     const uint64_t row = rows[rhome + (k - C) * step_z + (j - C) * step_y];
                     const int r = j * W + k;
-                    const uint32_t in =
-                        (inside[r / ROWS_PER_REG] >> ((r % ROWS_PER_REG) * W)) & ((1u << W) - 1u);
-                    valid[k] = (uint32_t)(row >> rx) & in;
+                    const uint32_t in4 = (inside[r / ROWS_PER_REG] >> ((r % ROWS_PER_REG) * W)) &
+                                         (((1u << W) - 1u) << 2);
+                    valid[k] = (uint32_t)(row >> rx) & in4;      // 4 * (occupied & inside)
                 }
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     if (RHO3 && NM_BOUNDS_RHO3.rb[j * W + k].b < 0) continue;
-                    const uint32_t t = lut[valid[k]];
+                    const uint32_t t = lut[valid[k] >> 2];
                     aj[j] += t;
                     bk[k] += t;
                     if (W <= 7)
