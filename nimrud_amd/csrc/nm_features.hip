@@ -820,7 +820,7 @@ __global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
 __global__ void k_publish_info(const uint32_t* counters, int64_t* info)
 {
     if (threadIdx.x == 0) {
-        info[0] = counters[1];   // M
+        info[0] = counters[3] ? -1 : (int64_t)counters[1];   // M (-1: the index build timed out)
         info[1] = counters[8];   // neighborhoods with population < 2
         info[2] = counters[9];   // extra passes of the search kernel
         info[3] = counters[0];   // leaves
@@ -1166,7 +1166,6 @@ struct LadderLayout {
     size_t s_key_tmp, s_val_tmp, s_key, s_order, s_xyz;
     size_t q_key_tmp, q_val_tmp, q_key, q_order, q_xyz;
     size_t sort_temp, sort_temp_bytes;
-    size_t key2;                 // second key buffer (the first is s_key) for the pipelined build
     size_t index[2], index_bytes;
     size_t total;
 };
@@ -1203,7 +1202,6 @@ static void ladder_layout(int64_t nq, int64_t ns, const nm_lattice* lats, int n_
         if (il.total > index_bytes) index_bytes = il.total;
     }
     S->index_bytes = index_bytes;
-    S->key2 = take((size_t)ns * 8);
     S->index[0] = take(index_bytes);
     S->index[1] = take(index_bytes);
     S->total = off;
@@ -1305,7 +1303,6 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         NM_HIP(ctx, hipEventRecord(ordered, s));
         NM_HIP(ctx, hipStreamWaitEvent(build, ordered, 0));
     }
-    uint64_t* key_buf[2] = {(uint64_t*)(w + S.s_key), (uint64_t*)(w + S.key2)};
     for (int i = 0; i < n_scales; ++i) {
         const LatticeDev L = make_lattice_dev(&lats[i]);
         int32_t dmin = 0;
@@ -1321,8 +1318,8 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         const bool was_profiling = ctx->profiling;
         if (overlap) ctx->profiling = false;     // no stage marks on the auxiliary stream
         IndexDev I;
-        rc = nm_index_build_any(ctx, (const double*)(w + S.s_xyz), n_search, L, key_buf[b], il,
-                                w + S.index[b], &I, build);
+        rc = nm_index_build_any(ctx, (const double*)(w + S.s_xyz), n_search, L, il, w + S.index[b], &I,
+                                build);
         ctx->profiling = was_profiling;
         if (rc) return rc;
         if (overlap) {

@@ -27,7 +27,6 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
                    uint64_t* key_tmp, uint32_t* val_tmp, uint64_t* key_sorted, uint32_t* order,
                    void* sort_temp, size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
 
-// index of lattice L from a spatially coherent coordinate stream (no sort); key_buf is n u64 scratch
+// index of lattice L from a spatially coherent coordinate stream (no sort)
 int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
-                       uint64_t* key_buf, const IndexLayout& lay, void* index_mem, IndexDev* out,
-                       hipStream_t s);
+                       const IndexLayout& lay, void* index_mem, IndexDev* out, hipStream_t s);

@@ -550,10 +550,10 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
 // but neighbours in the stream are still neighbours in space, so runs of equal superblock / equal row
 // word are long.  duplicates are therefore squeezed out inside each wave (compare with the previous
 // key), and what is left goes through the hash table with atomics:
-//   k_index_keys_insert  cell keys of this scale (stored for the next kernel); run heads CAS their
-//                        superblock key into the table; a block's winners get leaf numbers from ONE
-//                        counter bump per block, zero their leaf and publish it
-//   k_index_bits_any     run tails atomicOr the run's bits into the leaf (no return value awaited)
+//   k_index_fused        phase 1: cell keys of this scale; run heads CAS their superblock key into the
+//                        table; a block's winners get leaf numbers from ONE counter bump per block, zero
+//                        their leaf and publish it.  phase 2: run tails OR the run's bits into the
+//                        leaf, through a per-block table in LDS (no return value awaited)
 //   k_count_voxels       M = set bits of the allocated leaves
 // ---------------------------------------------------------------------------------------------------
 
@@ -581,60 +581,94 @@ __device__ __forceinline__ uint64_t nm_point_key(const double* __restrict__ p, c
     return nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
 }
 
-// both builders are chains of dependent memory round trips (coordinates / key -> hash probe -> atomic),
-// and a CU can hold only 2048 threads: with one group of 64 keys in flight per wave the kernels ran at
-// the latency of those chains.  so every wave works on NM_GROUPS independent groups of 64 keys at a
-// time: their loads, probes and atomics are issued together.
-constexpr int NM_GROUPS = 4;
-static_assert(INDEX_ITERS % NM_GROUPS == 0, "groups must tile the wave's iterations");
+constexpr uint32_t BITS_EMPTY = 0xFFFFFFFFu;     // free slot of a block's row-word table
 
-// one pass over the coordinate stream: the keys are computed and stored for k_index_bits_any, and the
-// run heads go to the hash table.
-__global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restrict__ xyz, int64_t n,
-                                                           LatticeDev L, uint64_t* __restrict__ key,
-                                                           IndexDev I)
+// ---- the builder: both passes in one kernel -----------------------------------------------------------
+// it is a chain of dependent memory round trips (coordinates -> key -> table probe -> CAS; leaf number
+// -> atomic), so every wave works on FUSED_GROUPS independent groups of 64 points at a time, and the
+// block is kept small enough in LDS for the register budget to bound the occupancy.
+// (history: as two kernels - insert, then bits - the keys went through memory in between, 160 MB per
+// scale at 10 M points, and the second kernel probed the table again for every run: 0.95 ms for the five
+// scales of the benchmark against 0.69 ms now.)  the block keeps what the bit phase needs about its
+// points in LDS - the table slot of the point's superblock and the cell's 11 local bits - so the second
+// phase touches memory only for the leaf numbers and the bits themselves.
+//
+// a leaf number may belong to a superblock another block entered and has not published yet.  the
+// reader then waits for it.  that cannot deadlock: whoever entered a key is a running block, and a
+// block publishes its leaves before its own bit phase, i.e. before it ever waits for anybody.  the
+// wait is bounded all the same (counters[3] flags a timeout; the library then reports M = -1).
+constexpr uint32_t LEAF_PENDING = 0xFFFFFFFFu;     // what the 0xFF-filled table holds before publication
+constexpr uint32_t LEAF_NONE = 0xFFFFFFFEu;        // published: no room (capacity overflow)
+
+// a block owns FUSED_CHUNK points.  LDS per block: 4 B per point of stash + 4 B per point of scratch
+// (list of created slots, then the table of row words): 16 KB at 2048 points, so the register
+// budget (6 waves per SIMD), not LDS, bounds the occupancy; the kernel is a chain of dependent
+// memory operations and lives on the number of waves in flight.
+#ifndef NM_FUSED_ITERS
+#define NM_FUSED_ITERS 8
+#endif
+#ifndef NM_FUSED_GROUPS
+#define NM_FUSED_GROUPS 4
+#endif
+constexpr int FUSED_ITERS = NM_FUSED_ITERS;
+constexpr int FUSED_GROUPS = NM_FUSED_GROUPS;   // groups of 64 points a wave has in flight
+constexpr int FUSED_WAVE_KEYS = 64 * FUSED_ITERS;
+constexpr int FUSED_CHUNK = 4 * FUSED_WAVE_KEYS;
+constexpr int FUSED_TABLE = FUSED_CHUNK / 2;
+constexpr int FUSED_TABLE_BITS = FUSED_ITERS == 16 ? 11 : (FUSED_ITERS == 8 ? 10 : 9);
+static_assert(FUSED_ITERS % FUSED_GROUPS == 0 && (1 << FUSED_TABLE_BITS) == FUSED_TABLE, "fused build geometry");
+
+__global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ xyz, int64_t n,
+                                                     LatticeDev L, IndexDev I)
 {
-    __shared__ uint32_t won_slot[INDEX_CHUNK];
+    __shared__ uint32_t stash_slot[FUSED_CHUNK];     // table slot of the point's superblock
+    __shared__ uint16_t stash_local[FUSED_CHUNK];    // the cell's 11 bits inside the superblock
+    // phase 1 needs the list of created slots, phase 2 the bit table: same memory
+    __shared__ uint32_t scratch[2 * FUSED_TABLE];
     __shared__ uint32_t won_count;
     __shared__ uint32_t leaf_base;
+    static_assert(2 * FUSED_TABLE >= FUSED_CHUNK, "the list of created slots must fit the scratch");
+    uint32_t* won_slot = scratch;
+    uint32_t* t_word = scratch;
+    uint32_t* t_bits = scratch + FUSED_TABLE;
     if (threadIdx.x == 0) won_count = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
-    // superblock of the key just before this wave's first one
-    uint64_t carry = ~0ull;
-    if (wave_lo > 0 && wave_lo <= n) carry = nm_point_key(xyz + (wave_lo - 1) * 3, L) >> NM_LOCAL_BITS;
-    for (int it = 0; it < INDEX_ITERS; it += NM_GROUPS) {
+    const int64_t wave_lo = (int64_t)blockIdx.x * FUSED_CHUNK + (int64_t)w * FUSED_WAVE_KEYS;
+    const unsigned long long below = (2ull << lane) - 1ull;
+
+    // ---- phase 1: keys, run heads into the table, every point's (slot, local) into the stash
+    uint64_t carry = ~0ull;          // superblock of the previous point of this wave; none at its start:
+    uint32_t carry_slot = 0u;        // the first point of a wave always probes
+    for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {
         const int64_t base = wave_lo + (int64_t)it * 64;
         if (base >= n) break;
-        uint64_t sb[NM_GROUPS];
-        bool head[NM_GROUPS];
-        uint32_t slot[NM_GROUPS];
-        uint64_t peek[NM_GROUPS];
+        uint64_t sb[FUSED_GROUPS];
+        uint32_t local[FUSED_GROUPS];
+        bool valid[FUSED_GROUPS], head[FUSED_GROUPS];
+        uint32_t slot[FUSED_GROUPS];
+        uint64_t peek[FUSED_GROUPS];
 #pragma unroll
-        for (int g = 0; g < NM_GROUPS; ++g) {
+        for (int g = 0; g < FUSED_GROUPS; ++g) {
             const int64_t i = base + g * 64 + lane;
-            const bool valid = i < n;
-            uint64_t k = 0ull;
-            if (valid) {
-                k = nm_point_key(xyz + i * 3, L);
-                key[i] = k;
-            }
+            valid[g] = i < n;
+            uint64_t k = ~0ull;
+            if (valid[g]) k = nm_point_key(xyz + i * 3, L);
             sb[g] = k >> NM_LOCAL_BITS;
+            local[g] = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
             uint64_t prev = __shfl_up(sb[g], 1);
             if (lane == 0) prev = carry;
             carry = __shfl(sb[g], 63);
-            head[g] = valid && sb[g] != prev;
+            head[g] = valid[g] && sb[g] != prev;
         }
-        // first probe of all groups at once
 #pragma unroll
-        for (int g = 0; g < NM_GROUPS; ++g) {
+        for (int g = 0; g < FUSED_GROUPS; ++g) {
             slot[g] = nm_hash64(sb[g]) & I.hash_mask;
             peek[g] = head[g] ? I.hash[slot[g]].key : sb[g];
         }
 #pragma unroll
-        for (int g = 0; g < NM_GROUPS; ++g) {
-            if (!head[g] || peek[g] == sb[g]) continue;      // already in the table
+        for (int g = 0; g < FUSED_GROUPS; ++g) {
+            if (!head[g] || peek[g] == sb[g]) continue;      // already in the table, at slot[g]
             uint32_t sl = slot[g];
             uint64_t pk = peek[g];
             for (;;) {
@@ -655,105 +689,104 @@ __global__ __launch_bounds__(256) void k_index_keys_insert(const double* __restr
                 sl = (sl + 1) & I.hash_mask;
                 pk = I.hash[sl].key;
             }
+            slot[g] = sl;
         }
-    }
-    __syncthreads();
-    const uint32_t total = won_count;
-    if (total == 0) return;
-    if (threadIdx.x == 0) leaf_base = atomicAdd(&I.counters[0], total);
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
-        const uint32_t idx = leaf_base + t;
-        if (idx >= I.leaf_capacity) {
-            I.counters[2] = 1u;
-            continue;
-        }
-        uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
+        // the slot of a point that is not a head is its run head's
 #pragma unroll
-        for (int q = 0; q < NM_LEAF_WORDS / 4; ++q) leaf[q] = make_uint4(0u, 0u, 0u, 0u);
-        I.hash[won_slot[t]].val = idx;
+        for (int g = 0; g < FUSED_GROUPS; ++g) {
+            const unsigned long long hm = __ballot(head[g]) & below;
+            const int src = hm ? 63 - __clzll((long long)hm) : 0;
+            uint32_t sl = __shfl(slot[g], src);
+            if (!hm) sl = carry_slot;
+            carry_slot = __shfl(sl, 63);
+            stash_slot[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane] = sl;
+            stash_local[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane] = (uint16_t)local[g];
+        }
     }
-}
-
-// the stream is in Z-order, so consecutive keys rarely share a row word and almost every key would cost
-// a global atomic.  a block's 4096 keys are a compact patch of space, though: they touch far fewer row
-// words than there are keys.  so the block first ORs its bits into a small table in LDS (LDS atomics
-// are local to the CU) and then sends one global atomic per distinct row word.
-constexpr int BITS_TABLE = 4096;              // LDS slots (word index + bits): 32 KB per block
-constexpr uint32_t BITS_EMPTY = 0xFFFFFFFFu;
-
-__global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restrict__ key, int64_t n,
-                                                        IndexDev I)
-{
-    __shared__ uint32_t t_word[BITS_TABLE];
-    __shared__ uint32_t t_bits[BITS_TABLE];
-    for (int t = threadIdx.x; t < BITS_TABLE; t += blockDim.x) {
+    __syncthreads();
+    // ---- the block's new leaves: one counter bump, zeroed, then published
+    const uint32_t total = won_count;
+    if (total) {
+        if (threadIdx.x == 0) leaf_base = atomicAdd(&I.counters[0], total);
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
+            const uint32_t idx = leaf_base + t;
+            if (idx < I.leaf_capacity) {
+                // device-scope stores: they go through to memory, where the other blocks' atomics
+                // on this leaf will execute (a plain store would sit in this XCD's L2 until a
+                // release fence writes the whole L2 back - measured: 8x slower kernel)
+                unsigned long long* leaf = (unsigned long long*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
+#pragma unroll
+                for (int q = 0; q < NM_LEAF_WORDS / 2; ++q)
+                    __hip_atomic_store(leaf + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                I.counters[2] = 1u;
+            }
+        }
+        // the zeroes must have arrived before anyone can learn the leaf number
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
+            const uint32_t idx = leaf_base + t;
+            __hip_atomic_store(&I.hash[won_slot[t]].val, idx < I.leaf_capacity ? idx : LEAF_NONE,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: the bits.  (the scratch now is the table of row words)
+    for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
         t_word[t] = BITS_EMPTY;
         t_bits[t] = 0u;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wave_lo = (int64_t)blockIdx.x * INDEX_CHUNK + (int64_t)w * INDEX_WAVE_KEYS;
-    const unsigned long long below = (2ull << lane) - 1ull;
-    for (int it = 0; it < INDEX_ITERS; it += NM_GROUPS) {
-        const int64_t base = wave_lo + (int64_t)it * 64;
-        if (base >= n) break;
-        uint64_t k[NM_GROUPS];
-        bool valid[NM_GROUPS], row_head[NM_GROUPS], sb_head[NM_GROUPS];
+    for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {
+        if (wave_lo + (int64_t)it * 64 >= n) break;
+        uint32_t sl[FUSED_GROUPS], loc[FUSED_GROUPS];
+        bool valid[FUSED_GROUPS], row_head[FUSED_GROUPS], sb_head[FUSED_GROUPS];
+        uint32_t val[FUSED_GROUPS];
 #pragma unroll
-        for (int g = 0; g < NM_GROUPS; ++g) {
-            const int64_t i = base + g * 64 + lane;
-            valid[g] = i < n;
-            k[g] = valid[g] ? key[i] : 0ull;
-        }
-        uint32_t slot[NM_GROUPS];
-        uint4 entry[NM_GROUPS];
-#pragma unroll
-        for (int g = 0; g < NM_GROUPS; ++g) {
-            const uint64_t prev = __shfl_up(k[g], 1);
+        for (int g = 0; g < FUSED_GROUPS; ++g) {
+            sl[g] = stash_slot[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane];
+            loc[g] = stash_local[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane];
+            valid[g] = wave_lo + (int64_t)(it + g) * 64 + lane < n;
+            const uint32_t prev_sl = __shfl_up(sl[g], 1);
+            const uint32_t prev_loc = __shfl_up(loc[g], 1);
             // runs are delimited inside one group of 64 only: lane 0 always starts one
-            row_head[g] = lane == 0 || (k[g] >> NM_SBX_BITS) != (prev >> NM_SBX_BITS) || !valid[g];
-            sb_head[g] = lane == 0 || (k[g] >> NM_LOCAL_BITS) != (prev >> NM_LOCAL_BITS) || !valid[g];
-            // first probe of every group's run heads, all in flight together
-            slot[g] = nm_hash64(k[g] >> NM_LOCAL_BITS) & I.hash_mask;
-            entry[g] = make_uint4(0u, 0u, 0u, 0u);
-            if (sb_head[g] && valid[g]) entry[g] = *(const uint4*)&I.hash[slot[g]];
+            sb_head[g] = lane == 0 || sl[g] != prev_sl || !valid[g];
+            row_head[g] = sb_head[g] || (loc[g] >> NM_SBX_BITS) != (prev_loc >> NM_SBX_BITS);
+            val[g] = LEAF_NONE;
+            if (sb_head[g] && valid[g])
+                val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int g = 0; g < NM_GROUPS; ++g) {
-            int32_t leaf = -1;
+        for (int g = 0; g < FUSED_GROUPS; ++g) {
             if (sb_head[g] && valid[g]) {
-                const uint64_t want = k[g] >> NM_LOCAL_BITS;
-                uint4 e = entry[g];
-                uint32_t sl = slot[g];
-                for (;;) {
-                    const uint64_t have = (uint64_t)e.x | ((uint64_t)e.y << 32);
-                    if (have == want) {
-                        leaf = (int32_t)e.z;
-                        break;
-                    }
-                    if (have == NM_HASH_EMPTY) break;
-                    sl = (sl + 1) & I.hash_mask;
-                    e = *(const uint4*)&I.hash[sl];
+                // not published yet: its creator is still in phase 1
+                for (int spin = 0; val[g] == LEAF_PENDING && spin < (1 << 22); ++spin) {
+                    __builtin_amdgcn_s_sleep(8);
+                    val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (val[g] == LEAF_PENDING) {
+                    I.counters[3] = 1u;
+                    val[g] = LEAF_NONE;
                 }
             }
             const unsigned long long sbm = __ballot(sb_head[g]);
-            leaf = __shfl(leaf, 63 - __clzll((long long)(sbm & below)));
+            const int32_t leaf = (int32_t)__shfl(val[g], 63 - __clzll((long long)(sbm & below)));
             const unsigned long long rowm = __ballot(row_head[g]);
             const int seg_start = 63 - __clzll((long long)(rowm & below));
-            uint32_t bits = valid[g] ? (1u << ((uint32_t)k[g] & 31u)) : 0u;
+            uint32_t bits = valid[g] ? (1u << (loc[g] & 31u)) : 0u;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t other = __shfl_up(bits, off);
                 if (lane - off >= seg_start) bits |= other;
             }
-            const int64_t i = base + g * 64 + lane;
-            const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull) || i + 1 >= n);
+            const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull));
             if (tail && leaf >= 0) {
-                const uint32_t local = (uint32_t)k[g] & ((1u << NM_LOCAL_BITS) - 1u);
-                const uint32_t word = (uint32_t)leaf * NM_LEAF_WORDS + (local >> NM_SBX_BITS);
-                // into the block's table; a few probes, then straight to memory if the table is crowded
-                uint32_t ts = (word * 0x9E3779B1u) >> (32 - 12);
+                const uint32_t word = (uint32_t)leaf * NM_LEAF_WORDS + (loc[g] >> NM_SBX_BITS);
+                uint32_t ts = (word * 0x9E3779B1u) >> (32 - FUSED_TABLE_BITS);
                 bool stored = false;
 #pragma unroll 1
                 for (int probe = 0; probe < 8; ++probe) {
@@ -763,16 +796,14 @@ __global__ __launch_bounds__(256) void k_index_bits_any(const uint64_t* __restri
                         stored = true;
                         break;
                     }
-                    ts = (ts + 1) & (BITS_TABLE - 1);
+                    ts = (ts + 1) & (FUSED_TABLE - 1);
                 }
-                // no return value wanted: the wave does not wait for the atomic.  M is counted
-                // afterwards from the leaves (k_count_voxels)
                 if (!stored) atomicOr(&I.leaf[word], bits);
             }
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < BITS_TABLE; t += blockDim.x) {
+    for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
         const uint32_t word = t_word[t];
         if (word != BITS_EMPTY) atomicOr(&I.leaf[word], t_bits[t]);
     }
@@ -916,8 +947,7 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
 }
 
 int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
-                       uint64_t* key_buf, const IndexLayout& lay, void* index_mem, IndexDev* out,
-                       hipStream_t s)
+                       const IndexLayout& lay, void* index_mem, IndexDev* out, hipStream_t s)
 {
     char* w = (char*)index_mem;
     IndexDev I;
@@ -929,9 +959,7 @@ int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const L
     NM_HIP(ctx, hipMemsetAsync(I.hash, 0xFF, (size_t)lay.hash_capacity * sizeof(HashEntry), s));
     NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
     nm_profile_mark(ctx, s);      // end of the "keys" stage (order build), start of the "index" stage
-    const int blocks = (int)((n + INDEX_CHUNK - 1) / INDEX_CHUNK);
-    k_index_keys_insert<<<blocks, 256, 0, s>>>(sorted_xyz, n, L, key_buf, I);
-    k_index_bits_any<<<blocks, 256, 0, s>>>(key_buf, n, I);
+    k_index_fused<<<(int)((n + FUSED_CHUNK - 1) / FUSED_CHUNK), 256, 0, s>>>(sorted_xyz, n, L, I);
     k_count_voxels<<<512, 256, 0, s>>>(I);
     NM_HIP(ctx, hipGetLastError());
     *out = I;
