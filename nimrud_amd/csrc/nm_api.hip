@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_forest_eval(nm_forest F, const double* 
 // float32 anyway), transposed so that lane t reads bank t % 32 whatever feature it needs; a node visit
 // is one 16-byte record load and one LDS read.
 constexpr int NM_FOREST_MAX_FEATURES = 40;
+constexpr int NM_FOREST_TREES = 8;     // trees descended side by side per thread
 
 struct PackedNode {
     double threshold;
@@ -159,18 +160,37 @@ __global__ __launch_bounds__(256) void k_forest_eval_packed(nm_forest F, const d
     double acc[NM_MAX_CLASSES];
 #pragma unroll
     for (int c = 0; c < NM_MAX_CLASSES; ++c) acc[c] = 0.0;
-    for (int t = 0; t < F.n_trees; ++t) {
-        int32_t node = F.d_packed_roots[t];
-        PackedNode rec = nodes[node];
-        while (rec.left >= 0) {
-            const double v = (double)xs[rec.feature * 256 + threadIdx.x];
-            node = rec.left + (v <= rec.threshold ? 0 : 1);
-            rec = nodes[node];
-        }
-        const double* val = F.d_leaf_value + (int64_t)rec.feature * F.n_classes;
+    // a descent is a chain of dependent record loads (L2 latency each): NM_FOREST_TREES trees go down
+    // side by side so that their loads overlap (5.9 -> 3.6 ms for 10 M rows x 32 trees of depth 12;
+    // keeping the top levels of the trees in LDS on top of that bought nothing).  the votes are still
+    // added in tree order.
+    for (int t0 = 0; t0 < F.n_trees; t0 += NM_FOREST_TREES) {
+        PackedNode rec[NM_FOREST_TREES];
 #pragma unroll
-        for (int c = 0; c < NM_MAX_CLASSES; ++c)
-            if (c < F.n_classes) acc[c] += val[c];
+        for (int g = 0; g < NM_FOREST_TREES; ++g) {
+            const int t = t0 + g < F.n_trees ? t0 + g : F.n_trees - 1;
+            rec[g] = nodes[F.d_packed_roots[t]];
+        }
+        bool any = true;
+        while (any) {
+            any = false;
+#pragma unroll
+            for (int g = 0; g < NM_FOREST_TREES; ++g) {
+                if (rec[g].left >= 0) {
+                    const double v = (double)xs[rec[g].feature * 256 + threadIdx.x];
+                    rec[g] = nodes[rec[g].left + (v <= rec[g].threshold ? 0 : 1)];
+                    any = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NM_FOREST_TREES; ++g) {
+            if (t0 + g >= F.n_trees) break;
+            const double* val = F.d_leaf_value + (int64_t)rec[g].feature * F.n_classes;
+#pragma unroll
+            for (int c = 0; c < NM_MAX_CLASSES; ++c)
+                if (c < F.n_classes) acc[c] += val[c];
+        }
     }
     int best = 0;
     double bestv = -1.0;

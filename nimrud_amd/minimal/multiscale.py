@@ -20,6 +20,7 @@ occupancy index -> fused search/moments/eigen kernel.  see DESIGN.md.
 """
 
 import ctypes
+import functools
 import time
 
 import numpy as np
@@ -63,6 +64,24 @@ def _scale_into(rt, query, search, shared, lo, hi, edge_length, radius, out_view
         _device.ptr(work), work.numel(), rt.stream()))
 
 
+@functools.lru_cache(maxsize=32)
+def _ladder_lattices(lo, hi, edge_lengths):
+    """the nm_lattice array of a ladder over a cloud with extrema lo, hi (VoxelFilter.__init__,
+    geometry.py:37-64, per scale).  a pure function of three tuples of floats, and a dozen small numpy
+    calls per scale: remembered, because a pipeline calls the ladder on the same cloud again and again
+    (the extrema themselves are still measured on the device at every call)."""
+    from nimrud_amd import _ffi
+    lats = (_ffi.NmLattice * len(edge_lengths))()
+    for s, e in enumerate(edge_lengths):
+        min_corner, _, widths, _ = geometry.lattice_parameters(np.asarray(lo), np.asarray(hi), e)
+        if np.any(widths < 1):
+            # the reference fails here too: int("0b" + "1"*0, 2) at geometry.py:74
+            raise ValueError("cloud has no extent beyond one voxel on some axis")
+        lat = geometry.make_nm_lattice(min_corner, e, widths)
+        ctypes.memmove(ctypes.byref(lats[s]), ctypes.byref(lat), ctypes.sizeof(_ffi.NmLattice))
+    return lats
+
+
 def _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info, knn_min=0,
                  knn_radius_factor=3.0):
     """enqueue the whole ladder in one library call (nm_multiscale_features): the cloud is sorted
@@ -71,11 +90,8 @@ def _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, in
     # the fallback switch is context state in the C ABI: always set it, so no call inherits another's
     rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
     n_scales = len(edge_lengths)
-    lats = (_ffi.NmLattice * n_scales)()
-    for s, e in enumerate(edge_lengths):
-        vf = geometry.VoxelFilter.from_bounds(lo, hi, e, device=rt.device)
-        ctypes.memmove(ctypes.byref(lats[s]), ctypes.byref(vf.nm_lattice),
-                       ctypes.sizeof(_ffi.NmLattice))
+    lats = _ladder_lattices(tuple(float(v) for v in lo), tuple(float(v) for v in hi),
+                            tuple(float(e) for e in edge_lengths))
     rad = (ctypes.c_double * n_scales)(*[float(r) for r in radii])
     nq, ns = query.shape[0], search.shape[0]
     nbytes = rt.lib.nm_multiscale_workspace_bytes(nq, ns, lats, n_scales)
