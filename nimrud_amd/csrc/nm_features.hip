@@ -43,6 +43,9 @@ struct ScaleArgs {
     double* feat;
     int64_t fstride;
     uint32_t* stats;         // [0] neighborhoods with population < 2, [1] extra passes
+    // kNN fallback on: one bit per slot, set where the population came out below sparse_k (else null)
+    unsigned long long* sparse;
+    int32_t sparse_k;
 };
 
 // ---- 3x3 symmetric eigenvalues, fp64, non-iterative ------------------------------------------------
@@ -739,6 +742,10 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
     const unsigned long long degenerate = __ballot(emit && m_n < 2u);
     if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
         atomicAdd(&A.stats[0], (uint32_t)__popcll(degenerate));
+    if (A.sparse) {
+        const unsigned long long sparse = __ballot(have && (far || m_n < (uint32_t)A.sparse_k));
+        if (lane == 0) A.sparse[batch] = sparse;
+    }
 }
 
 // ---- generic kernel: any W, direct index lookups per lane (no staging).  slow path for unusual
@@ -839,18 +846,69 @@ struct KnnArgs {
     int32_t k;
     double rk2;
     int32_t max_shell;
+    const uint32_t* list;      // slots whose population is below k, compacted
+    const uint32_t* count;
 };
+
+// the sparse bits of the generic kernel's slots (the table kernels write theirs on the way)
+__global__ __launch_bounds__(64) void k_knn_mark(ScaleArgs A)
+{
+    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    bool sparse = false;
+    if (slot < A.n_slots) {
+        const uint32_t qi = A.order[slot];
+        if (qi < A.nq) sparse = A.feat[(int64_t)qi * A.fstride] < (double)A.sparse_k;
+    }
+    const unsigned long long m = __ballot(sparse);
+    if (threadIdx.x == 0) A.sparse[blockIdx.x] = m;
+}
+
+// bits -> list of slots.  one counter atomic per block of 256 words (16 k slots)
+__global__ __launch_bounds__(256) void k_knn_compact(const unsigned long long* __restrict__ mask,
+                                                     int64_t n_words, uint32_t* __restrict__ list,
+                                                     uint32_t* __restrict__ count)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t base;
+    const int64_t wi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long m = wi < n_words ? mask[wi] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(m);
+    // inclusive scan inside the wave, then across the block's four waves
+    uint32_t incl = c;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < w) before += wsum[i];
+        total += wsum[i];
+    }
+    if (threadIdx.x == 0) base = total ? atomicAdd(count, total) : 0u;
+    __syncthreads();
+    uint32_t at = base + before + incl - c;
+    while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        list[at++] = (uint32_t)(wi * 64 + bit);
+    }
+}
 
 __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
 {
     const ScaleArgs& A = K.S;
     const LatticeDev& L = A.L;
-    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (slot >= A.n_slots) return;
+    // the launch covers every slot; the waves beyond the list leave at once
+    const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (idx >= (int64_t)*K.count) return;
+    const int64_t slot = K.list[idx];
     const uint32_t qi = A.order[slot];
-    if (qi >= A.nq) return;
     double* o = A.feat + (int64_t)qi * A.fstride;
-    if (o[0] >= (double)K.k) return;
     const double* p = A.query + (A.direct ? slot : (int64_t)qi) * A.qstride;
     const double qx = p[0], qy = p[1], qz = p[2];
     const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
@@ -859,6 +917,7 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
 
     double bd[NM_KNN_MAX];
     int64_t bc[NM_KNN_MAX];      // address-like code of the voxel: tie break and offsets
+    double kth_best = INFINITY;  // bd[k-1]: a candidate beyond it cannot be among the k nearest
     int32_t found = 0;
     // two stages: a small cube first - most sparse neighborhoods find their k voxels just outside the
     // radius - and the full cube only when the k-th best is not yet provably final (every cell outside
@@ -870,6 +929,7 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
         bc[t] = INT64_MAX;
     }
     found = 0;
+    kth_best = INFINITY;
     // walk the leaves that intersect the cube of half-width S around the home cell: one hash lookup per
     // leaf, then its 64 row words; only occupied cells cost a distance.  sparse neighborhoods (the only
     // ones that get here) touch few leaves.
@@ -908,7 +968,7 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
                             double cd = (d * d + dy2) + dz2;
                             if (!(cd <= K.rk2)) continue;
                             ++found;
-                            if (cd > bd[NM_KNN_MAX - 1]) continue;      // cannot enter the list
+                            if (cd > kth_best) continue;      // cannot be among the k nearest
                             // offsets from the home cell, biased, z high / x low: the same order as
                             // the reference's voxel address, which is the tie break
                             int64_t cc = ((int64_t)(gz - hz + 1024) << 22) |
@@ -923,6 +983,9 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
                                 cd = td;
                                 cc = tc;
                             }
+#pragma unroll
+                            for (int t = 0; t < NM_KNN_MAX; ++t)
+                                if (t == K.k - 1) kth_best = bd[t];
                         }
                     }
                 }
@@ -958,11 +1021,35 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
     o[3] = out[3];
 }
 
-static void launch_knn_fallback(nm_ctx* ctx, const ScaleArgs& A, double radius, hipStream_t s)
+// workspace of the fallback: the sparse bits, the compacted slots, their count
+struct KnnLayout {
+    size_t mask, list, count, total;
+};
+
+static void knn_layout(int64_t n_slots, size_t* off, KnnLayout* Kl)
 {
-    if (ctx->knn_k <= 0 || A.nq <= 0) return;
+    auto take = [&](size_t bytes) {
+        size_t at = *off;
+        *off += (bytes + 255) / 256 * 256;
+        return at;
+    };
+    Kl->mask = take((size_t)((n_slots + 63) / 64) * 8);
+    Kl->list = take((size_t)n_slots * 4);
+    Kl->count = take(256);
+}
+
+static int launch_knn_fallback(nm_ctx* ctx, const ScaleArgs& A, double radius, bool marked,
+                               uint32_t* list, uint32_t* count, hipStream_t s)
+{
+    if (ctx->knn_k <= 0 || A.nq <= 0) return NM_OK;
+    const int64_t n_words = (A.n_slots + 63) / 64;
+    if (!marked) k_knn_mark<<<(int)n_words, 64, 0, s>>>(A);
+    NM_HIP(ctx, hipMemsetAsync(count, 0, 4, s));
+    k_knn_compact<<<(int)((n_words + 255) / 256), 256, 0, s>>>(A.sparse, n_words, list, count);
     KnnArgs K;
     K.S = A;
+    K.list = list;
+    K.count = count;
     K.k = ctx->knn_k;
     const double rk = radius * ctx->knn_radius_factor;
     K.rk2 = rk * rk;
@@ -970,6 +1057,7 @@ static void launch_knn_fallback(nm_ctx* ctx, const ScaleArgs& A, double radius, 
     if (shells > 1000.0) shells = 1000.0;
     K.max_shell = (int32_t)shells;
     k_knn_fallback<<<(int)((A.n_slots + 63) / 64), 64, 0, s>>>(K);
+    return NM_OK;
 }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -986,7 +1074,8 @@ static int candidate_width(double radius, double edge, int32_t* dmin)
 }
 
 // picks the kernel instance for (W, r/e) and launches it
-static void launch_scale_kernel(const ScaleArgs& A, const nm_lattice* lat, double radius, int W,
+// returns true if the kernel it chose writes the sparse bits of the kNN fallback itself
+static bool launch_scale_kernel(const ScaleArgs& A, const nm_lattice* lat, double radius, int W,
                                 hipStream_t s)
 {
     // one workgroup per 64-query batch: the hardware dispatcher balances the uneven batches (waves
@@ -1014,8 +1103,9 @@ static void launch_scale_kernel(const ScaleArgs& A, const nm_lattice* lat, doubl
             else k_scale_features<7, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, prune));
             break;
         case 9: k_scale_features<9, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, prune)); break;
-        default: k_scale_features_generic<<<generic_blocks, 64, 0, s>>>(A); break;
+        default: k_scale_features_generic<<<generic_blocks, 64, 0, s>>>(A); return false;
     }
+    return true;
 }
 
 static int check_scale_args(nm_ctx* ctx, const char* who, const double* d_query, int64_t n_query,
@@ -1039,6 +1129,7 @@ struct ScaleLayout {
     size_t sort_temp, sort_temp_bytes;
     size_t index;
     IndexLayout ilay;
+    KnnLayout knn;
     size_t total;
 };
 
@@ -1066,6 +1157,7 @@ static void scale_layout(int64_t nq, int64_t ns, const LatticeDev& L, bool share
     S->sort_temp = take(S->sort_temp_bytes);
     nm_index_layout(L, ns, &S->ilay);
     S->index = take(S->ilay.total);
+    knn_layout(ns > nq ? ns : nq, &off, &S->knn);
     S->total = off;
 }
 
@@ -1150,8 +1242,12 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.feat = d_feat;
         A.fstride = feat_stride;
         A.stats = I.counters + 8;
-        launch_scale_kernel(A, lat, radius, W, s);
-        launch_knn_fallback(ctx, A, radius, s);
+        A.sparse = ctx->knn_k > 0 ? (unsigned long long*)(w + S.knn.mask) : nullptr;
+        A.sparse_k = ctx->knn_k;
+        const bool marked = launch_scale_kernel(A, lat, radius, W, s);
+        rc = launch_knn_fallback(ctx, A, radius, marked, (uint32_t*)(w + S.knn.list),
+                                 (uint32_t*)(w + S.knn.count), s);
+        if (rc) return rc;
     }
     nm_profile_mark(ctx, s);
     NM_HIP(ctx, hipGetLastError());
@@ -1167,6 +1263,7 @@ struct LadderLayout {
     size_t q_key_tmp, q_val_tmp, q_key, q_order, q_xyz;
     size_t sort_temp, sort_temp_bytes;
     size_t index[2], index_bytes;
+    KnnLayout knn;
     size_t total;
 };
 
@@ -1204,6 +1301,7 @@ static void ladder_layout(int64_t nq, int64_t ns, const nm_lattice* lats, int n_
     S->index_bytes = index_bytes;
     S->index[0] = take(index_bytes);
     S->index[1] = take(index_bytes);
+    knn_layout(ns > nq ? ns : nq, &off, &S->knn);
     S->total = off;
 }
 
@@ -1348,8 +1446,12 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
             A.feat = d_feat + 4 * i;
             A.fstride = feat_stride;
             A.stats = I.counters + 8;
-            launch_scale_kernel(A, &lats[i], radii[i], W, s);
-            launch_knn_fallback(ctx, A, radii[i], s);
+            A.sparse = ctx->knn_k > 0 ? (unsigned long long*)(w + S.knn.mask) : nullptr;
+            A.sparse_k = ctx->knn_k;
+            const bool marked = launch_scale_kernel(A, &lats[i], radii[i], W, s);
+            rc = launch_knn_fallback(ctx, A, radii[i], marked, (uint32_t*)(w + S.knn.list),
+                                     (uint32_t*)(w + S.knn.count), s);
+            if (rc) return rc;
         }
         nm_profile_mark(ctx, s);
         NM_HIP(ctx, hipGetLastError());
