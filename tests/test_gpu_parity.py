@@ -6,6 +6,8 @@ bar: population and neighbor indices bit-exact; eigen-features |a-b| <= 1e-5*|b|
 distance 1e-9 relative plus the fp64 representation error of the coordinates (conftest.py).
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -399,6 +401,29 @@ def test_ladder_call_is_bit_identical_to_per_scale_calls():
     assert torch.equal(c, d)
     want = oracle.process_fast(query.cpu().numpy(), pts, edges[:2], radii[:2])
     assert_features_close(c.cpu().numpy()[:, :8], want, pts)
+
+
+def test_plain_c_host_through_the_c_abi(tmp_path):
+    """examples/c_abi_demo.c: gcc-compiled C99, device buffers from hipMalloc, lattices built in C from
+    nm_bounds - no Python and no torch between the caller and libnimrud_hip.so.  same numbers as the
+    Python host, and as the oracle."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "c_abi_demo")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
+    pts, _ = synth.scene_cloud(60000, extent=12.0, n_poles=10, n_spheres=4, seed=515)
+    edges, radii = [0.05, 0.10, 0.20], [0.15, 0.30, 0.60]
+    src, dst = tmp_path / "points.f64", tmp_path / "features.f64"
+    np.ascontiguousarray(pts, dtype="<f8").tofile(src)
+    args = [exe, str(src), str(len(pts)), str(dst)]
+    for e, r in zip(edges, radii):
+        args += [repr(e), repr(r)]
+    done = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr
+    got = np.fromfile(dst, dtype="<f8").reshape(len(pts), 4 * len(edges))
+    via_python = multiscale.process_single_core(pts, pts, edges, radii)
+    assert np.array_equal(got, via_python)
+    assert_features_close(got, oracle.process_c(pts, pts, edges, radii), pts)
 
 
 # ---- edge cases --------------------------------------------------------------------------------------
