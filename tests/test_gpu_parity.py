@@ -200,6 +200,37 @@ def test_oracle_sparse_cloud_many_passes():
     assert info[0].extra_passes > 0
 
 
+def test_index_builder_extremes():
+    """the fused index builder at its corners, through the ladder call, against the C oracle:
+    (a) every point in a superblock of its own, in an order that is not spatial for the coarser scales
+        (each block creates as many leaves as it has points; other blocks wait for their publication);
+    (b) a wide, nearly empty lattice (20+ address bits per axis: 64-bit superblock keys, long probe
+        sequences) holding two dense clusters far apart;
+    (c) one hundred thousand copies of a handful of cells (one leaf, maximal run lengths)."""
+    rs = np.random.RandomState(733)
+    # (a) 60 k isolated points on a jittered coarse grid, 40 cells apart at the finest scale
+    g = np.stack(np.meshgrid(np.arange(40), np.arange(40), np.arange(40), indexing="ij"), -1).reshape(-1, 3)
+    sparse = (g[rs.permutation(len(g))[:60000]] * 4.0 + rs.rand(60000, 3) * 0.5)
+    # (b) two clusters 3 km apart at e = 0.05: widths of 17 bits and more
+    a = synth.uniform_cloud(30000, extent=2.0, seed=734)
+    b = synth.uniform_cloud(30000, extent=2.0, seed=735) + np.array([3000.0, 2500.0, 40.0])
+    wide = np.concatenate((a, b))
+    # (c) duplicates
+    few = rs.rand(7, 3) * 0.3
+    dup = few[rs.randint(0, 7, size=100000)] + rs.rand(100000, 3) * 1e-9
+    for pts, edges, radii in ((sparse, [0.1, 0.2, 0.4], [0.3, 0.6, 1.2]),
+                              (wide, [0.05, 0.1], [0.15, 0.3]),
+                              (dup, [0.05, 0.1], [0.15, 0.3])):
+        dev = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
+        got, info = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
+        want = oracle.process_c(pts, pts, edges, radii)
+        assert_features_close(got.cpu().numpy(), want, pts)
+        per_scale, info2 = multiscale.process_gpu(dev, dev, edges, radii, return_info=True, per_scale=True)
+        assert torch.equal(got, per_scale)
+        for x, y in zip(info, info2):
+            assert x.voxels == y.voxels and x.leaves == y.leaves and x.voxels > 0
+
+
 def test_strided_cloud_with_feature_columns():
     # (N, 3+F) clouds: geometry in the first three columns (minimal/README.md:38-40)
     pts = synth.uniform_cloud(5000, extent=3.0, seed=51)
