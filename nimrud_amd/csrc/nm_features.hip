@@ -834,6 +834,23 @@ __global__ void k_publish_info(const uint32_t* counters, int64_t* info)
     }
 }
 
+struct PublishList {
+    int32_t n;
+    const uint32_t* counters[NM_MAX_LADDER];
+};
+
+__global__ void k_publish_info_all(PublishList P, int64_t* info)
+{
+    const int i = threadIdx.x;
+    if (i < P.n) {
+        const uint32_t* counters = P.counters[i];
+        info[4 * i + 0] = counters[3] ? -1 : (int64_t)counters[1];
+        info[4 * i + 1] = counters[8];
+        info[4 * i + 2] = counters[9];
+        info[4 * i + 3] = counters[0];
+    }
+}
+
 // ---- k-nearest-voxel fallback -------------------------------------------------------------------------
 // queries whose radius neighborhood has fewer than k voxels are re-evaluated on their k nearest occupied
 // voxel centres within rk (rk2 = rk*rk).  one lane per query; the lane walks the index leaves that
@@ -1262,7 +1279,8 @@ struct LadderLayout {
     size_t s_key_tmp, s_val_tmp, s_key, s_order, s_xyz;
     size_t q_key_tmp, q_val_tmp, q_key, q_order, q_xyz;
     size_t sort_temp, sort_temp_bytes;
-    size_t index[2], index_bytes;
+    size_t index[NM_MAX_LADDER];     // one index per scale: they are cleared and counted together
+    IndexLayout ilay[NM_MAX_LADDER];
     KnnLayout knn;
     size_t total;
 };
@@ -1292,15 +1310,10 @@ static void ladder_layout(int64_t nq, int64_t ns, const nm_lattice* lats, int n_
     }
     S->sort_temp_bytes = nm_sort_pairs_temp_bytes(ns > nq ? ns : nq);
     S->sort_temp = take(S->sort_temp_bytes);
-    size_t index_bytes = 0;
-    for (int i = 0; i < n_scales; ++i) {
-        IndexLayout il;
-        nm_index_layout(make_lattice_dev(&lats[i]), ns, &il);
-        if (il.total > index_bytes) index_bytes = il.total;
+    for (int i = 0; i < n_scales && i < NM_MAX_LADDER; ++i) {
+        nm_index_layout(make_lattice_dev(&lats[i]), ns, &S->ilay[i]);
+        S->index[i] = take(S->ilay[i].total);
     }
-    S->index_bytes = index_bytes;
-    S->index[0] = take(index_bytes);
-    S->index[1] = take(index_bytes);
     knn_layout(ns > nq ? ns : nq, &off, &S->knn);
     S->total = off;
 }
@@ -1318,7 +1331,7 @@ static hipEvent_t ladder_event(nm_ctx* ctx, size_t i)
 extern "C" size_t nm_multiscale_workspace_bytes(int64_t n_query, int64_t n_search,
                                                 const nm_lattice* lats, int32_t n_scales)
 {
-    if (!lats || n_scales < 1 || n_query < 0 || n_search < 1) return 0;
+    if (!lats || n_scales < 1 || n_scales > NM_MAX_LADDER || n_query < 0 || n_search < 1) return 0;
     LadderLayout S;
     ladder_layout(n_query > 0 ? n_query : 1, n_search, lats, n_scales, false, &S);
     return S.total;
@@ -1335,6 +1348,8 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
     if (n_scales < 0 || (n_scales > 0 && (!lats || !radii)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: bad scale arguments");
     if (n_scales == 0) return NM_OK;
+    if (n_scales > NM_MAX_LADDER)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: at most %d scales per call", NM_MAX_LADDER);
     if (feat_stride < 4 * (int64_t)n_scales)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: feat_stride < 4 * n_scales");
     int rc = check_scale_args(ctx, "nm_multiscale_features", d_query, n_query, query_stride, d_search,
@@ -1383,8 +1398,15 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         q_xyz = (const double*)(w + S.q_xyz);
     }
 
+    // every scale has its own index; all of them are cleared by one launch here and counted by one
+    // launch at the end
+    IndexDev index[NM_MAX_LADDER];
+    for (int i = 0; i < n_scales; ++i) index[i] = nm_index_at(w + S.index[i], S.ilay[i]);
+    rc = nm_index_clear_all(ctx, index, n_scales, s);
+    if (rc) return rc;
+
     // pipelining: with overlap on (and profiling of the stages off) the index of scale i is built on
-    // the auxiliary stream into buffer i%2 while the caller's stream runs the kernel of scale i-1.
+    // the auxiliary stream while the caller's stream runs the kernel of scale i-1.
     const bool overlap = ctx->overlap && n_scales > 1;
     hipStream_t build = s;
     if (overlap) {
@@ -1405,19 +1427,11 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         const LatticeDev L = make_lattice_dev(&lats[i]);
         int32_t dmin = 0;
         const int W = candidate_width(radii[i], lats[i].edge, &dmin);
-        IndexLayout il;
-        nm_index_layout(L, n_search, &il);
-        const int b = overlap ? (i & 1) : 0;
-        if (overlap && i >= 2) {
-            // buffer b was last read by the kernel of scale i-2
-            NM_HIP(ctx, hipStreamWaitEvent(build, ladder_event(ctx, 1 + 2 * (i - 2) + 1), 0));
-        }
         if (!overlap && i > 0) nm_profile_mark(ctx, s);
         const bool was_profiling = ctx->profiling;
         if (overlap) ctx->profiling = false;     // no stage marks on the auxiliary stream
-        IndexDev I;
-        rc = nm_index_build_any(ctx, (const double*)(w + S.s_xyz), n_search, L, il, w + S.index[b], &I,
-                                build);
+        const IndexDev I = index[i];
+        rc = nm_index_build_any(ctx, (const double*)(w + S.s_xyz), n_search, L, I, build);
         ctx->profiling = was_profiling;
         if (rc) return rc;
         if (overlap) {
@@ -1455,12 +1469,15 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         }
         nm_profile_mark(ctx, s);
         NM_HIP(ctx, hipGetLastError());
-        if (d_info) k_publish_info<<<1, 64, 0, s>>>(I.counters, d_info + 4 * i);
-        if (overlap) {
-            hipEvent_t ran = ladder_event(ctx, 1 + 2 * i + 1);
-            if (!ran) NM_FAIL(ctx, NM_ERR_HIP, "could not create a HIP event");
-            NM_HIP(ctx, hipEventRecord(ran, s));
-        }
+    }
+    if (d_info) {
+        rc = nm_index_count_all(ctx, index, n_scales, s);
+        if (rc) return rc;
+        PublishList P;
+        P.n = n_scales;
+        for (int i = 0; i < n_scales; ++i) P.counters[i] = index[i].counters;
+        k_publish_info_all<<<1, 64, 0, s>>>(P, d_info);
+        NM_HIP(ctx, hipGetLastError());
     }
     return NM_OK;
 }

@@ -27,6 +27,11 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
                    uint64_t* key_tmp, uint32_t* val_tmp, uint64_t* key_sorted, uint32_t* order,
                    void* sort_temp, size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
 
-// index of lattice L from a spatially coherent coordinate stream (no sort)
+// ---- the ladder's indexes: one per scale, cleared and counted together --------------------------------
+constexpr int NM_MAX_LADDER = 32;     // scales per nm_multiscale_features call
+IndexDev nm_index_at(void* index_mem, const IndexLayout& lay);
+int nm_index_clear_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s);
+int nm_index_count_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s);
+// index of lattice L from a spatially coherent coordinate stream (no sort), into a cleared index
 int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
-                       const IndexLayout& lay, void* index_mem, IndexDev* out, hipStream_t s);
+                       const IndexDev& I, hipStream_t s);

@@ -558,7 +558,7 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
 //                        table; a block's winners get leaf numbers from ONE counter bump per block, zero
 //                        their leaf and publish it.  phase 2: run tails OR the run's bits into the
 //                        leaf, through a per-block table in LDS (no return value awaited)
-//   k_count_voxels       M = set bits of the allocated leaves
+//   k_count_voxels_all   M = set bits of the allocated leaves, all scales of a ladder in one launch
 // ---------------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_gather_xyz(const double* __restrict__ xyz, int64_t n,
@@ -813,28 +813,6 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
     }
 }
 
-// M = number of set bits in the allocated leaves (counters[0] of them)
-__global__ __launch_bounds__(256) void k_count_voxels(IndexDev I)
-{
-    __shared__ uint32_t wsum[4];
-    const uint32_t n_leaves = min(I.counters[0], I.leaf_capacity);
-    const uint64_t words = (uint64_t)n_leaves * NM_LEAF_WORDS / 4;     // as uint4
-    uint32_t c = 0;
-    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < words;
-         t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 v = ((const uint4*)I.leaf)[t];
-        c += (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t) atomicAdd(&I.counters[1], t);
-    }
-}
-
 // 3-D Morton (Z-order) code of a cell, 21 bits per axis.  used only for the one-time spatial sort of the
 // whole-ladder path: a Z-order run of points is compact in all three axes at EVERY coarser scale,
 // which keeps the boxes the search kernel stages small (a column-major order scatters vertical
@@ -962,8 +940,7 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
     return NM_OK;
 }
 
-int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
-                       const IndexLayout& lay, void* index_mem, IndexDev* out, hipStream_t s)
+IndexDev nm_index_at(void* index_mem, const IndexLayout& lay)
 {
     char* w = (char*)index_mem;
     IndexDev I;
@@ -972,12 +949,79 @@ int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const L
     I.counters = (uint32_t*)w;
     I.hash_mask = lay.hash_capacity - 1;
     I.leaf_capacity = lay.leaf_capacity;
-    NM_HIP(ctx, hipMemsetAsync(I.hash, 0xFF, (size_t)lay.hash_capacity * sizeof(HashEntry), s));
-    NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
+    return I;
+}
+
+// the ladder keeps one index per scale and prepares / finishes them together: a launch that clears a few
+// megabytes or counts a few thousand leaves costs 5-8 us of which almost nothing is work, and there were
+// four of them per scale.
+struct IndexList {
+    int32_t n;
+    IndexDev I[NM_MAX_LADDER];
+};
+
+// hash tables to all ones (free), counter blocks to zero
+__global__ __launch_bounds__(256) void k_index_clear_all(IndexList Lst)
+{
+    const IndexDev& I = Lst.I[blockIdx.y];
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint4* h = (uint4*)I.hash;
+    const uint64_t slots = (uint64_t)I.hash_mask + 1ull;
+    for (uint64_t i = tid; i < slots; i += stride)
+        h[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (tid < 64) I.counters[tid] = 0u;
+}
+
+// M of every index (set bits of its allocated leaves)
+__global__ __launch_bounds__(256) void k_count_voxels_all(IndexList Lst)
+{
+    __shared__ uint32_t wsum[4];
+    const IndexDev& I = Lst.I[blockIdx.y];
+    const uint32_t n_leaves = min(I.counters[0], I.leaf_capacity);
+    const uint64_t words = (uint64_t)n_leaves * NM_LEAF_WORDS / 4;     // as uint4
+    uint32_t c = 0;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < words;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = ((const uint4*)I.leaf)[t];
+        c += (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(&I.counters[1], t);
+    }
+}
+
+int nm_index_clear_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s)
+{
+    IndexList L;
+    L.n = n;
+    for (int i = 0; i < n; ++i) L.I[i] = list[i];
+    k_index_clear_all<<<dim3(256, n), 256, 0, s>>>(L);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+int nm_index_count_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s)
+{
+    IndexList L;
+    L.n = n;
+    for (int i = 0; i < n; ++i) L.I[i] = list[i];
+    k_count_voxels_all<<<dim3(128, n), 256, 0, s>>>(L);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+// fills an index that nm_index_clear_all has prepared; its voxel count comes from nm_index_count_all
+int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
+                       const IndexDev& I, hipStream_t s)
+{
     nm_profile_mark(ctx, s);      // end of the "keys" stage (order build), start of the "index" stage
     k_index_fused<<<(int)((n + FUSED_CHUNK - 1) / FUSED_CHUNK), 256, 0, s>>>(sorted_xyz, n, L, I);
-    k_count_voxels<<<512, 256, 0, s>>>(I);
     NM_HIP(ctx, hipGetLastError());
-    *out = I;
     return NM_OK;
 }
