@@ -72,11 +72,11 @@ int         nm_abi_version(void);
  * used by bench.py for the roofline figure; no reference counterpart (the reference's verbose mode
  * prints wall time per scale, multiscale.py:47-65).                                                */
 int nm_profile_begin(nm_ctx* ctx);
-/* nm_multiscale_features builds the occupancy index of scale i+1 on an internal auxiliary stream
- * while the fused kernel of scale i runs on the caller's stream (the caller's stream still orders the
- * whole call).  OFF by default: on MI355X the long VALU-bound kernel starves the second queue, so the
- * pipelined form measured no faster.  with overlap on, only ms[2] of the profile is
- * meaningful.                                                                                    */
+/* nm_multiscale_features builds the occupancy indexes on an internal auxiliary stream while the fused
+ * kernels run on the caller's stream (the caller's stream still orders the whole call).  OFF by
+ * default: measured 2 % faster per step on MI355X (the VALU-bound kernel and the latency-bound builders
+ * share the CUs, there is little to gain), but the in-library stage timing then only has a meaningful
+ * ms[2], and that includes the slowdown of the kernels by the concurrent builders.                 */
 int nm_set_overlap(nm_ctx* ctx, int enabled);
 int nm_profile_end(nm_ctx* ctx, double* ms, int64_t* launches);
 

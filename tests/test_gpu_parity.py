@@ -434,6 +434,26 @@ def test_ladder_call_is_bit_identical_to_per_scale_calls():
     assert_features_close(c.cpu().numpy()[:, :8], want, pts)
 
 
+def test_pipelined_ladder_is_bit_identical():
+    """nm_set_overlap(1): the indexes are built on the library's auxiliary stream while the caller's
+    stream runs the search kernels.  same bits, same counters."""
+    from nimrud_amd import device
+    rt = device.get_runtime()
+    pts, _ = synth.scene_cloud(300000, extent=35.0, n_poles=40, n_spheres=10, seed=606)
+    edges, radii = [0.05, 0.10, 0.20, 0.40, 0.80], [0.15, 0.30, 0.60, 1.20, 2.40]
+    dev = torch.from_numpy(pts).cuda()
+    a, ia = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
+    try:
+        rt.check(rt.lib.nm_set_overlap(rt.ctx, 1))
+        for _ in range(3):
+            b, ib = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
+            assert torch.equal(a, b)
+            assert [(x.voxels, x.leaves, x.degenerate) for x in ia] == \
+                   [(x.voxels, x.leaves, x.degenerate) for x in ib]
+    finally:
+        rt.check(rt.lib.nm_set_overlap(rt.ctx, 0))
+
+
 def test_plain_c_host_through_the_c_abi(tmp_path):
     """examples/c_abi_demo.c: gcc-compiled C99, device buffers from hipMalloc, lattices built in C from
     nm_bounds - no Python and no torch between the caller and libnimrud_hip.so.  same numbers as the
