@@ -161,6 +161,12 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
 
     if strict or return_info:
         host = info.cpu().numpy()
+        if (host[:n_scales, 0] < 0).any():
+            # the index builder's bounded wait for a leaf number ran out (csrc/nm_index.hip): the
+            # occupancy index, and with it every feature of that scale, is incomplete
+            from nimrud_amd import _ffi
+            raise _ffi.NimrudHipError("occupancy index build timed out at scale(s) %s"
+                                      % np.flatnonzero(host[:n_scales, 0] < 0).tolist())
         if strict and host[:n_scales, 1].any():
             raise FloatingPointError(
                 "%d neighborhoods have fewer than 2 voxels; their covariance is undefined "
