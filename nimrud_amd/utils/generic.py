@@ -1,22 +1,37 @@
 """
-small helpers shared by the pipeline.  mirrors nimrud/utils/generic.py (batcher, :8-26).
+host-side helpers of the pipeline.
+
+`batcher` has the call signature and the results of the reference's helper of the same name
+(nimrud/utils/generic.py:8-26), which the reference uses to walk a query cloud in chunks of
+QUERY_CHUNK_SIZE (multiscale.py:94).  the GPU path has no use for query chunks - a kernel launch takes
+the whole cloud - so here it is a convenience for callers that stream clouds from disk, and it also
+understands torch tensors (device-resident clouds are cut into views, nothing is copied).
 """
 
 import itertools
 
 import numpy as np
+import torch
+
+_SLICEABLE = (np.ndarray, list, torch.Tensor)
+
+
+def _lazy_groups(iterable, size):
+    source = iter(iterable)
+    group = list(itertools.islice(source, size))
+    while group:
+        yield group
+        group = list(itertools.islice(source, size))
 
 
 def batcher(collection, chunk_size):
-    """yield consecutive chunks of `chunk_size` items.  arrays and lists are sliced; any other
-    iterable is consumed lazily and yielded as lists (last chunk may be short)."""
-    if isinstance(collection, (np.ndarray, list)):
-        for start in range(0, len(collection), chunk_size):
-            yield collection[start:start + chunk_size]
-        return
-    iterator = iter(collection)
-    while True:
-        chunk = list(itertools.islice(iterator, chunk_size))
-        if not chunk:
-            return
-        yield chunk
+    """generator over consecutive pieces of `collection`, `chunk_size` items each (the last one may be
+    shorter).  anything that can be sliced comes back as slices of itself; any other iterable is read
+    only as far as needed and comes back as lists."""
+    chunk_size = int(chunk_size)
+    if chunk_size < 1:
+        raise ValueError("chunk_size must be at least 1")
+    if not isinstance(collection, _SLICEABLE):
+        return _lazy_groups(collection, chunk_size)
+    total = len(collection)
+    return (collection[lo:min(lo + chunk_size, total)] for lo in range(0, total, chunk_size))

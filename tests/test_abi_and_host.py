@@ -107,6 +107,11 @@ def test_batcher():
     assert list(generic.batcher([1, 2, 3], 2)) == [[1, 2], [3]]
     assert list(generic.batcher(iter(range(5)), 2)) == [[0, 1], [2, 3], [4]]
     assert list(generic.batcher(iter(()), 2)) == []
+    assert list(generic.batcher((1, 2, 3), 2)) == [[1, 2], [3]]       # not sliced: like the reference
+    import torch
+    t = torch.arange(5)
+    assert [c.tolist() for c in generic.batcher(t, 2)] == [[0, 1], [2, 3], [4]]
+    assert next(iter(generic.batcher(t, 2))).data_ptr() == t.data_ptr()    # views, no copies
 
 
 def test_synthetic_clouds_are_deterministic_and_fp32_representable():
