@@ -158,6 +158,17 @@ int nm_multiscale_features(nm_ctx* ctx,
  * (oracle.one_scale_knn: cKDTree.query on the same voxel set).                                       */
 int nm_set_knn_fallback(nm_ctx* ctx, int k_min, double radius_factor);
 
+/* ---- covariance output (legacy C_MSO, prototypes/mso.py:1555) -----------------
+ * while d_cov is not NULL, nm_scale_features / nm_multiscale_features also write, per query row and
+ * scale s, the upper triangle [xx, xy, xz, yy, yz, zz] of the ddof=1 covariance of the neighborhood's
+ * voxel centres - the matrix features.pca forms with numpy.cov (features.py:43) before it takes its
+ * eigenvalues - to d_cov[row * cov_stride + 6*s + 0..5] (nm_scale_features: s = 0), in the cloud's
+ * units squared.  neighborhoods with fewer than 2 voxels give zeros; rows re-evaluated by the kNN
+ * fallback get the covariance of the kNN set.  pass NULL to switch it off again.  the reference returns
+ * only the two normalised eigenvalues (features.py:57); this is an opt-in extra, checked against
+ * numpy.cov on the oracle's neighborhoods.                                                          */
+int nm_set_covariance_output(nm_ctx* ctx, double* d_cov, int64_t cov_stride);
+
 /* ---- neighbor lists (parity / inspection mode) -----------------------------------------------------
  * the neighbor_idx lists of multiscale.py:103 as CSR.  two calls: with d_nbr_index == NULL the
  * per-query counts are written to d_nbr_count (int32[n_query]); the caller turns them into offsets

@@ -19,7 +19,7 @@ NM_ERR_WORKSPACE = -3
 NM_ERR_HIP = -4
 NM_ERR_RADIUS = -5
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i64 = ctypes.c_int64
 c_i32 = ctypes.c_int32
@@ -54,6 +54,7 @@ SIGNATURES = {
     "nm_set_knn_fallback": (ctypes.c_int, [c_ptr, ctypes.c_int, c_f64]),
     "nm_profile_begin": (ctypes.c_int, [c_ptr]),
     "nm_set_overlap": (ctypes.c_int, [c_ptr, ctypes.c_int]),
+    "nm_set_covariance_output": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64]),
     "nm_profile_end": (ctypes.c_int, [c_ptr, ctypes.POINTER(c_f64 * 4), ctypes.POINTER(c_i64)]),
     "nm_bounds": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "nm_voxelize_workspace_bytes": (c_size, [c_i64]),

@@ -5,7 +5,7 @@
 
 #include "nm_common.h"
 
-extern "C" int nm_abi_version(void) { return 2; }
+extern "C" int nm_abi_version(void) { return 3; }
 
 extern "C" int nm_create(nm_ctx** out, int device)
 {
@@ -46,6 +46,16 @@ extern "C" int nm_set_knn_fallback(nm_ctx* ctx, int k_min, double radius_factor)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_knn_fallback: k_min in [0,16], radius_factor >= 1");
     ctx->knn_k = k_min;
     if (k_min > 0) ctx->knn_radius_factor = radius_factor;
+    return NM_OK;
+}
+
+extern "C" int nm_set_covariance_output(nm_ctx* ctx, double* d_cov, int64_t cov_stride)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (d_cov && cov_stride < 6)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_covariance_output: cov_stride must be at least 6");
+    ctx->cov_out = d_cov;
+    ctx->cov_stride = d_cov ? cov_stride : 0;
     return NM_OK;
 }
 

@@ -46,6 +46,9 @@ struct ScaleArgs {
     // kNN fallback on: one bit per slot, set where the population came out below sparse_k (else null)
     unsigned long long* sparse;
     int32_t sparse_k;
+    // covariance output on: upper triangle per row (already offset to this scale's six columns), else null
+    double* cov;
+    int64_t cstride;
 };
 
 // ---- 3x3 symmetric eigenvalues, fp64, non-iterative ------------------------------------------------
@@ -297,6 +300,25 @@ __device__ __forceinline__ void nm_features_from_moments(
     out[3] = l1 * inv_tr;
 }
 
+// upper triangle of the ddof=1 covariance (features.py:43) from the integer moments; gy, gz = -1 where
+// the moments were taken in a frame mirrored on that axis.  cov = e^2 (n S2 - S1 S1^T) / (n (n - 1))
+__device__ __forceinline__ void nm_covariance_from_moments(
+    double n, double sx, double sy, double sz, double sxx, double sxy, double sxz, double syy,
+    double syz, double szz, double gy, double gz, double edge, double* __restrict__ c)
+{
+    if (n < 2.0) {
+        c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = 0.0;
+        return;
+    }
+    const double f = edge * edge / (n * (n - 1.0));
+    c[0] = (n * sxx - sx * sx) * f;
+    c[1] = (n * sxy - sx * sy) * f * gy;
+    c[2] = (n * sxz - sx * sz) * f * gz;
+    c[3] = (n * syy - sy * sy) * f;
+    c[4] = (n * syz - sy * sz) * f * (gy * gz);
+    c[5] = (n * szz - sz * sz) * f;
+}
+
 // wave-wide min / max of an int32 with DPP row operations (6 VALU instructions + a readlane) instead
 // of 6 rounds through the LDS crossbar: quad swaps, half-row and row mirrors leave every row of 16
 // lanes holding its own result, row_bcast15 / row_bcast31 fold the four rows into lane 63.
@@ -513,6 +535,10 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         o[1] = 0.0;
         o[2] = 0.0;
         o[3] = 0.0;
+        if (A.cov) {
+            double* c = A.cov + (int64_t)qi * A.cstride;
+            c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = 0.0;
+        }
     }
 
     // reflect the window in y and z so that the query is in the upper half of its home cell there
@@ -738,6 +764,11 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         o[1] = out[1];
         o[2] = out[2];
         o[3] = out[3];
+        if (A.cov)
+            nm_covariance_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
+                                       (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
+                                       (double)m_syz, (double)m_szz, (double)sgn_y, (double)sgn_z,
+                                       L.edge, A.cov + (int64_t)qi * A.cstride);
     }
     const unsigned long long degenerate = __ballot(emit && m_n < 2u);
     if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
@@ -817,6 +848,9 @@ __global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
     o[1] = out[1];
     o[2] = out[2];
     o[3] = out[3];
+    if (A.cov)
+        nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
+                                   A.cov + (int64_t)qi * A.cstride);
     if (n < 2.0) atomicAdd(&A.stats[0], 1u);
 }
 
@@ -1036,6 +1070,9 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
     o[1] = out[1];
     o[2] = out[2];
     o[3] = out[3];
+    if (A.cov)
+        nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
+                                   A.cov + (int64_t)qi * A.cstride);
 }
 
 // workspace of the fallback: the sparse bits, the compacted slots, their count
@@ -1261,6 +1298,8 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.stats = I.counters + 8;
         A.sparse = ctx->knn_k > 0 ? (unsigned long long*)(w + S.knn.mask) : nullptr;
         A.sparse_k = ctx->knn_k;
+        A.cov = ctx->cov_out;
+        A.cstride = ctx->cov_stride;
         const bool marked = launch_scale_kernel(A, lat, radius, W, s);
         rc = launch_knn_fallback(ctx, A, radius, marked, (uint32_t*)(w + S.knn.list),
                                  (uint32_t*)(w + S.knn.count), s);
@@ -1352,6 +1391,8 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: at most %d scales per call", NM_MAX_LADDER);
     if (feat_stride < 4 * (int64_t)n_scales)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: feat_stride < 4 * n_scales");
+    if (ctx->cov_out && ctx->cov_stride < 6 * (int64_t)n_scales)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: covariance stride < 6 * n_scales");
     int rc = check_scale_args(ctx, "nm_multiscale_features", d_query, n_query, query_stride, d_search,
                               n_search, search_stride, d_feat, feat_stride, d_work);
     if (rc) return rc;
@@ -1462,6 +1503,8 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
             A.stats = I.counters + 8;
             A.sparse = ctx->knn_k > 0 ? (unsigned long long*)(w + S.knn.mask) : nullptr;
             A.sparse_k = ctx->knn_k;
+            A.cov = ctx->cov_out ? ctx->cov_out + 6 * i : nullptr;
+            A.cstride = ctx->cov_stride;
             const bool marked = launch_scale_kernel(A, &lats[i], radii[i], W, s);
             rc = launch_knn_fallback(ctx, A, radii[i], marked, (uint32_t*)(w + S.knn.list),
                                      (uint32_t*)(w + S.knn.count), s);

@@ -104,8 +104,22 @@ def _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, in
         _device.ptr(work), work.numel(), rt.stream()))
 
 
+def _report_scale(rt, verbose, nq, info, s, this_edge, this_radius, inner_start):
+    """the reference's per-scale progress lines (multiscale.py:47-65)."""
+    if not verbose:
+        return
+    torch.cuda.synchronize(rt.device)
+    inner = time.perf_counter() - inner_start
+    print("querying {} points against a search space of {} voxels".format(nq, int(info[s, 0])))
+    print("using a voxel edge length of {} and radius of {}".format(this_edge, this_radius))
+    print("this scale took {}s".format(np.around(inner, 6)))
+    print("one scale rate of {} points per second".format(np.around(nq / inner, 3)))
+    print("===================================")
+
+
 def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, strict=False,
-                return_info=False, out=None, per_scale=False, knn_min=0, knn_radius_factor=3.0):
+                return_info=False, out=None, per_scale=False, knn_min=0, knn_radius_factor=3.0,
+                cov_out=None):
     """process_single_core for clouds resident in HBM: torch GPU tensors in, (Nq, 4*S) fp64 GPU tensor
     out.  nothing crosses PCIe except six doubles (the search cloud's extrema) and, when strict or
     return_info, 4 counters per scale.
@@ -113,7 +127,10 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
     verbose=True or per_scale=True runs one self-contained call per scale instead (same numbers).
     knn_min > 0 switches on the k-nearest-voxel fallback (an extension the reference does not have,
     BASELINE config 4): neighborhoods with fewer than knn_min voxels take their centroid and eigen
-    features from the knn_min nearest voxels within knn_radius_factor * radius."""
+    features from the knn_min nearest voxels within knn_radius_factor * radius.
+    cov_out, a (Nq, 6*S) fp64 GPU tensor, additionally receives per scale the upper triangle
+    [xx, xy, xz, yy, yz, zz] of the neighborhood covariance whose eigenvalues the features are
+    (see process_gpu_covariance)."""
     assert len(edge_lengths) == len(radii), \
         "edge_lengths and radii should be equal-length sequences."
     shared = query_cloud is search_cloud
@@ -131,28 +148,39 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
     if n_scales == 0:
         return (out, []) if return_info else out
 
+    if cov_out is not None:
+        if not (isinstance(cov_out, torch.Tensor) and cov_out.dtype == torch.float64 and
+                cov_out.device == out.device and cov_out.ndim == 2 and cov_out.shape[0] == nq and
+                cov_out.shape[1] >= 6 * n_scales and cov_out.stride(1) == 1):
+            raise ValueError("cov_out must be a (Nq, >= 6*S) fp64 tensor on the clouds' device")
     outer_start = time.perf_counter()
     lo, hi = _device.cloud_bounds(rt, search)
     rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
-    if not (verbose or per_scale):
-        _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info,
-                     knn_min=knn_min, knn_radius_factor=knn_radius_factor)
-        edge_lengths_loop = []
-    else:
-        edge_lengths_loop = list(zip(edge_lengths, radii))
-    for s, (this_edge, this_radius) in enumerate(edge_lengths_loop):
-        inner_start = time.perf_counter()
-        _scale_into(rt, query, search, shared, lo, hi, this_edge, this_radius,
-                    out[:, 4 * s:4 * s + 4], info[s])
-        if verbose:
-            torch.cuda.synchronize(rt.device)
-            inner = time.perf_counter() - inner_start
-            print("querying {} points against a search space of {} voxels".format(
-                nq, int(info[s, 0])))
-            print("using a voxel edge length of {} and radius of {}".format(this_edge, this_radius))
-            print("this scale took {}s".format(np.around(inner, 6)))
-            print("one scale rate of {} points per second".format(np.around(nq / inner, 3)))
-            print("===================================")
+
+    def covariance_columns(first_scale):
+        # context state of the C ABI, like the fallback switch: set for this call, cleared after it
+        if cov_out is None:
+            return
+        rt.check(rt.lib.nm_set_covariance_output(
+            rt.ctx, ctypes.c_void_p(cov_out.data_ptr() + 48 * first_scale), int(cov_out.stride(0))))
+
+    try:
+        if not (verbose or per_scale):
+            covariance_columns(0)
+            _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info,
+                         knn_min=knn_min, knn_radius_factor=knn_radius_factor)
+            edge_lengths_loop = []
+        else:
+            edge_lengths_loop = list(zip(edge_lengths, radii))
+        for s, (this_edge, this_radius) in enumerate(edge_lengths_loop):
+            inner_start = time.perf_counter()
+            covariance_columns(s)
+            _scale_into(rt, query, search, shared, lo, hi, this_edge, this_radius,
+                        out[:, 4 * s:4 * s + 4], info[s])
+            _report_scale(rt, verbose, nq, info, s, this_edge, this_radius, inner_start)
+    finally:
+        if cov_out is not None:
+            rt.check(rt.lib.nm_set_covariance_output(rt.ctx, None, 0))
     if verbose:
         torch.cuda.synchronize(rt.device)
         outer = time.perf_counter() - outer_start
@@ -175,6 +203,17 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
         if return_info:
             return out, [ScaleInfo(row) for row in host[:n_scales]]
     return out
+
+
+def process_gpu_covariance(query_cloud, search_cloud, edge_lengths, radii, **kwargs):
+    """(features (Nq, 4*S), covariances (Nq, 6*S)): per scale the four features and the upper triangle
+    [xx, xy, xz, yy, yz, zz] of the ddof=1 covariance of the neighborhood's voxel centres - the matrix
+    features.pca builds with numpy.cov (features.py:43).  zeros where fewer than 2 voxels."""
+    rt, search = _device.as_cloud(search_cloud)
+    nq = search.shape[0] if query_cloud is search_cloud else _device.as_cloud(query_cloud, rt.device)[1].shape[0]
+    cov = torch.zeros((nq, 6 * len(edge_lengths)), dtype=torch.float64, device=rt.device)
+    feats = process_gpu(query_cloud, search_cloud, edge_lengths, radii, cov_out=cov, **kwargs)
+    return feats, cov
 
 
 def one_scale_gpu(query_cloud, search_cloud, edge_length, radius, verbose=False, strict=False):

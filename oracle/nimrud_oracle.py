@@ -220,6 +220,24 @@ def one_scale(query_cloud, search_cloud, edge_length, radius, strict=False, retu
     return out
 
 
+def one_scale_covariance(query_cloud, search_cloud, edge_length, radius):
+    """(Nq,6): upper triangle [xx, xy, xz, yy, yz, zz] of numpy.cov(neighborhood, rowvar=False) - the
+    matrix features.pca forms at features.py:43 before taking its eigenvalues; zeros where the
+    neighborhood has fewer than 2 voxels.  the reference does not return it (only the two normalised
+    eigenvalues, features.py:57): this restates an intermediate of a pinned function."""
+    query_xyz = np.asarray(query_cloud, dtype=np.float64)[:, :3]
+    search_xyz = np.asarray(search_cloud, dtype=np.float64)[:, :3]
+    lattice = Lattice(search_xyz, edge_length)
+    voxels = lattice.unique_voxels(search_xyz)
+    nbrs = ball_neighbors_kdtree(query_xyz, voxels, radius)
+    out = np.zeros((len(query_xyz), 6))
+    iu = np.triu_indices(3)
+    for i, idx in enumerate(nbrs):
+        if len(idx) >= 2:
+            out[i] = np.cov(voxels.take(idx, axis=0), rowvar=False)[iu]
+    return out
+
+
 def process(query_cloud, search_cloud, edge_lengths, radii, strict=False):
     """(Nq, 4*S): per-scale blocks concatenated column-wise in caller order (multiscale.py:27-67)"""
     assert len(edge_lengths) == len(radii), \

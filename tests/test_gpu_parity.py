@@ -434,6 +434,54 @@ def test_ladder_call_is_bit_identical_to_per_scale_calls():
     assert_features_close(c.cpu().numpy()[:, :8], want, pts)
 
 
+def test_covariance_output_against_numpy_cov():
+    """nm_set_covariance_output: the ddof=1 covariance numpy.cov gives for the oracle's neighborhoods
+    (features.py:43), through the ladder call, the per-scale calls, the generic kernel (r/e = 5.5) and
+    the kNN fallback; and its normalised eigenvalues are the features of the same row."""
+    pts, _ = synth.scene_cloud(2500, extent=6.0, n_poles=4, n_spheres=2, seed=818)
+    pts = pts + np.array([120.0, -45.0, 7.0])
+    edges, radii = [0.10, 0.20, 0.1], [0.30, 0.60, 0.55]
+    dev = torch.from_numpy(pts).cuda()
+    feats, cov = multiscale.process_gpu_covariance(dev, dev, edges, radii)
+    feats2, cov2 = multiscale.process_gpu_covariance(dev, dev, edges, radii, per_scale=True)
+    assert torch.equal(cov, cov2) and torch.equal(feats, feats2)
+    assert torch.equal(feats, multiscale.process_gpu(dev, dev, edges, radii))
+    got = cov.cpu().numpy()
+    f = feats.cpu().numpy()
+    for s, (e, r) in enumerate(zip(edges, radii)):
+        want = oracle.one_scale_covariance(pts, pts, e, r)
+        c = got[:, 6 * s:6 * s + 6]
+        scale = np.abs(want).max()
+        assert np.abs(c - want).max() <= 1e-9 * scale
+        few = f[:, 4 * s] < 2
+        assert np.all(c[few] == 0.0)
+        # eigenvalues of the 3x3 it describes, normalised, are columns 2 and 3
+        m = np.zeros((len(c), 3, 3))
+        iu = np.triu_indices(3)
+        m[:, iu[0], iu[1]] = c
+        m[:, iu[1], iu[0]] = c
+        w = np.linalg.eigvalsh(m)[:, ::-1]
+        ok = ~few & (w.sum(1) > 0)
+        assert np.abs(w[ok, 0] / w[ok].sum(1) - f[ok, 4 * s + 2]).max() < 1e-9
+        assert np.abs(w[ok, 1] / w[ok].sum(1) - f[ok, 4 * s + 3]).max() < 1e-9
+    # with the fallback on, sparse rows carry the covariance of their k nearest voxels: still consistent
+    rs = np.random.RandomState(819)
+    sparse = rs.rand(3000, 3) * 6.0
+    sdev = torch.from_numpy(sparse).cuda()
+    fk, ck = multiscale.process_gpu_covariance(sdev, sdev, [0.1], [0.3], knn_min=6)
+    fk, ck = fk.cpu().numpy(), ck.cpu().numpy()
+    m = np.zeros((len(ck), 3, 3))
+    iu = np.triu_indices(3)
+    m[:, iu[0], iu[1]] = ck
+    m[:, iu[1], iu[0]] = ck
+    w = np.linalg.eigvalsh(m)[:, ::-1]
+    ok = w.sum(1) > 0
+    assert ok.sum() > 1000
+    assert np.abs(w[ok, 0] / w[ok].sum(1) - fk[ok, 2]).max() < 1e-9
+    # the switch is cleared after the call
+    assert torch.equal(multiscale.process_gpu(dev, dev, edges, radii), feats)
+
+
 def test_pipelined_ladder_is_bit_identical():
     """nm_set_overlap(1): the indexes are built on the library's auxiliary stream while the caller's
     stream runs the search kernels.  same bits, same counters."""
