@@ -169,6 +169,16 @@ int nm_set_knn_fallback(nm_ctx* ctx, int k_min, double radius_factor);
  * numpy.cov on the oracle's neighborhoods.                                                          */
 int nm_set_covariance_output(nm_ctx* ctx, double* d_cov, int64_t cov_stride);
 
+/* ---- surface normal output (legacy OG_MSO, prototypes/mso.py:1315) -------------
+ * while d_normal is not NULL, the same calls also write, per query row and scale s, the unit
+ * eigenvector of the SMALLEST eigenvalue of that covariance - the normal of the best-fitting plane - to
+ * d_normal[row * normal_stride + 3*s + 0..2].  the sign is fixed by making the last non-zero component
+ * in the order x, y, z positive (normals point up).  zeros for neighborhoods with fewer than 3 voxels;
+ * where the two smallest eigenvalues (nearly) coincide the direction is not defined by the data and
+ * the vector is some unit vector of that eigenspace.  opt-in extra, checked against numpy.linalg.eigh
+ * on the oracle's neighborhoods.  pass NULL to switch it off.                                        */
+int nm_set_normal_output(nm_ctx* ctx, double* d_normal, int64_t normal_stride);
+
 /* ---- neighbor lists (parity / inspection mode) -----------------------------------------------------
  * the neighbor_idx lists of multiscale.py:103 as CSR.  two calls: with d_nbr_index == NULL the
  * per-query counts are written to d_nbr_count (int32[n_query]); the caller turns them into offsets

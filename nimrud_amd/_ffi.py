@@ -55,6 +55,7 @@ SIGNATURES = {
     "nm_profile_begin": (ctypes.c_int, [c_ptr]),
     "nm_set_overlap": (ctypes.c_int, [c_ptr, ctypes.c_int]),
     "nm_set_covariance_output": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64]),
+    "nm_set_normal_output": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64]),
     "nm_profile_end": (ctypes.c_int, [c_ptr, ctypes.POINTER(c_f64 * 4), ctypes.POINTER(c_i64)]),
     "nm_bounds": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "nm_voxelize_workspace_bytes": (c_size, [c_i64]),

@@ -59,6 +59,16 @@ extern "C" int nm_set_covariance_output(nm_ctx* ctx, double* d_cov, int64_t cov_
     return NM_OK;
 }
 
+extern "C" int nm_set_normal_output(nm_ctx* ctx, double* d_normal, int64_t normal_stride)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (d_normal && normal_stride < 3)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_normal_output: normal_stride must be at least 3");
+    ctx->normal_out = d_normal;
+    ctx->normal_stride = d_normal ? normal_stride : 0;
+    return NM_OK;
+}
+
 extern "C" int nm_profile_begin(nm_ctx* ctx)
 {
     if (!ctx) return NM_ERR_INVALID;

@@ -25,6 +25,8 @@ struct nm_ctx {
     // k-nearest-voxel fallback for sparse neighborhoods (nm_set_knn_fallback); 0 = off
     double* cov_out = nullptr;   // nm_set_covariance_output
     int64_t cov_stride = 0;
+    double* normal_out = nullptr;   // nm_set_normal_output
+    int64_t normal_stride = 0;
     int knn_k = 0;
     double knn_radius_factor = 3.0;
 };

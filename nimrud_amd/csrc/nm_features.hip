@@ -49,6 +49,9 @@ struct ScaleArgs {
     // covariance output on: upper triangle per row (already offset to this scale's six columns), else null
     double* cov;
     int64_t cstride;
+    // normal output on: three columns per row (already offset to this scale), else null
+    double* normal;
+    int64_t nstride;
 };
 
 // ---- 3x3 symmetric eigenvalues, fp64, non-iterative ------------------------------------------------
@@ -319,6 +322,59 @@ __device__ __forceinline__ void nm_covariance_from_moments(
     c[5] = (n * szz - sz * sz) * f;
 }
 
+// unit eigenvector of the smallest eigenvalue of n S2 - S1 S1^T (the plane normal of the neighborhood), in
+// the true frame (gy, gz = -1 where the moments were taken mirrored), last non-zero of (x, y, z) positive.
+// the smallest eigenvalue comes from the robust solver; its eigenvector is the largest cross product of
+// two rows of A - lambda I, on the matrix scaled to unit size.
+__device__ __forceinline__ void nm_normal_from_moments(
+    double n, double sx, double sy, double sz, double sxx, double sxy, double sxz, double syy,
+    double syz, double szz, double gy, double gz, double* __restrict__ v)
+{
+    v[0] = v[1] = v[2] = 0.0;
+    if (n < 3.0) return;
+    double a00 = n * sxx - sx * sx, a01 = n * sxy - sx * sy, a02 = n * sxz - sx * sz;
+    double a11 = n * syy - sy * sy, a12 = n * syz - sy * sz, a22 = n * szz - sz * sz;
+    const double tr = a00 + a11 + a22;
+    if (!(tr > 0.0)) return;
+    const double inv = 1.0 / tr;
+    a00 *= inv; a01 *= inv; a02 *= inv; a11 *= inv; a12 *= inv; a22 *= inv;
+    double l0, l1, l2;
+    nm_eig3(a00, a01, a02, a11, a12, a22, l0, l1, l2);
+    const double m00 = a00 - l2, m11 = a11 - l2, m22 = a22 - l2;
+    double x0 = a01 * a12 - a02 * m11, y0 = a02 * a01 - m00 * a12, z0 = m00 * m11 - a01 * a01;
+    double x1 = a01 * m22 - a02 * a12, y1 = a02 * a02 - m00 * m22, z1 = m00 * a12 - a01 * a02;
+    double x2 = m11 * m22 - a12 * a12, y2 = a12 * a02 - a01 * m22, z2 = a01 * a12 - m11 * a02;
+    const double n0 = x0 * x0 + y0 * y0 + z0 * z0, n1 = x1 * x1 + y1 * y1 + z1 * z1,
+                 n2 = x2 * x2 + y2 * y2 + z2 * z2;
+    double vx = x0, vy = y0, vz = z0, nn = n0;
+    if (n1 > nn) { vx = x1; vy = y1; vz = z1; nn = n1; }
+    if (n2 > nn) { vx = x2; vy = y2; vz = z2; nn = n2; }
+    if (!(nn > 0.0)) {
+        // A - lambda I has rank <= 1: every direction orthogonal to its one row direction will do
+        vx = 0.0; vy = 0.0; vz = 1.0;
+        const double r0 = m00 * m00 + a01 * a01 + a02 * a02, r1 = a01 * a01 + m11 * m11 + a12 * a12,
+                     r2 = a02 * a02 + a12 * a12 + m22 * m22;
+        double rx = m00, ry = a01, rz = a02, rr = r0;
+        if (r1 > rr) { rx = a01; ry = m11; rz = a12; rr = r1; }
+        if (r2 > rr) { rx = a02; ry = a12; rz = m22; rr = r2; }
+        if (rr > 0.0) {
+            // a vector orthogonal to (rx, ry, rz)
+            if (fabs(rx) > fabs(rz)) { vx = -ry; vy = rx; vz = 0.0; }
+            else { vx = 0.0; vy = -rz; vz = ry; }
+            if (vx == 0.0 && vy == 0.0 && vz == 0.0) { vx = 1.0; }
+        }
+        nn = vx * vx + vy * vy + vz * vz;
+    }
+    const double s = 1.0 / sqrt(nn);
+    vx *= s;
+    vy *= s * gy;
+    vz *= s * gz;
+    const bool flip = vz < 0.0 || (vz == 0.0 && (vy < 0.0 || (vy == 0.0 && vx < 0.0)));
+    v[0] = flip ? -vx : vx;
+    v[1] = flip ? -vy : vy;
+    v[2] = flip ? -vz : vz;
+}
+
 // wave-wide min / max of an int32 with DPP row operations (6 VALU instructions + a readlane) instead
 // of 6 rounds through the LDS crossbar: quad swaps, half-row and row mirrors leave every row of 16
 // lanes holding its own result, row_bcast15 / row_bcast31 fold the four rows into lane 63.
@@ -538,6 +594,10 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         if (A.cov) {
             double* c = A.cov + (int64_t)qi * A.cstride;
             c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = 0.0;
+        }
+        if (A.normal) {
+            double* v = A.normal + (int64_t)qi * A.nstride;
+            v[0] = v[1] = v[2] = 0.0;
         }
     }
 
@@ -769,6 +829,11 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                                        (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
                                        (double)m_syz, (double)m_szz, (double)sgn_y, (double)sgn_z,
                                        L.edge, A.cov + (int64_t)qi * A.cstride);
+        if (A.normal)
+            nm_normal_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz, (double)m_sxx,
+                                   (double)m_sxy, (double)m_sxz, (double)m_syy, (double)m_syz,
+                                   (double)m_szz, (double)sgn_y, (double)sgn_z,
+                                   A.normal + (int64_t)qi * A.nstride);
     }
     const unsigned long long degenerate = __ballot(emit && m_n < 2u);
     if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
@@ -851,6 +916,9 @@ __global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
     if (A.cov)
         nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
                                    A.cov + (int64_t)qi * A.cstride);
+    if (A.normal)
+        nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0,
+                               A.normal + (int64_t)qi * A.nstride);
     if (n < 2.0) atomicAdd(&A.stats[0], 1u);
 }
 
@@ -1073,6 +1141,9 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
     if (A.cov)
         nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
                                    A.cov + (int64_t)qi * A.cstride);
+    if (A.normal)
+        nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0,
+                               A.normal + (int64_t)qi * A.nstride);
 }
 
 // workspace of the fallback: the sparse bits, the compacted slots, their count
@@ -1300,6 +1371,8 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.sparse_k = ctx->knn_k;
         A.cov = ctx->cov_out;
         A.cstride = ctx->cov_stride;
+        A.normal = ctx->normal_out;
+        A.nstride = ctx->normal_stride;
         const bool marked = launch_scale_kernel(A, lat, radius, W, s);
         rc = launch_knn_fallback(ctx, A, radius, marked, (uint32_t*)(w + S.knn.list),
                                  (uint32_t*)(w + S.knn.count), s);
@@ -1393,6 +1466,8 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: feat_stride < 4 * n_scales");
     if (ctx->cov_out && ctx->cov_stride < 6 * (int64_t)n_scales)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: covariance stride < 6 * n_scales");
+    if (ctx->normal_out && ctx->normal_stride < 3 * (int64_t)n_scales)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: normal stride < 3 * n_scales");
     int rc = check_scale_args(ctx, "nm_multiscale_features", d_query, n_query, query_stride, d_search,
                               n_search, search_stride, d_feat, feat_stride, d_work);
     if (rc) return rc;
@@ -1505,6 +1580,8 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
             A.sparse_k = ctx->knn_k;
             A.cov = ctx->cov_out ? ctx->cov_out + 6 * i : nullptr;
             A.cstride = ctx->cov_stride;
+            A.normal = ctx->normal_out ? ctx->normal_out + 3 * i : nullptr;
+            A.nstride = ctx->normal_stride;
             const bool marked = launch_scale_kernel(A, &lats[i], radii[i], W, s);
             rc = launch_knn_fallback(ctx, A, radii[i], marked, (uint32_t*)(w + S.knn.list),
                                      (uint32_t*)(w + S.knn.count), s);

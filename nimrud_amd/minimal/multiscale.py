@@ -119,7 +119,7 @@ def _report_scale(rt, verbose, nq, info, s, this_edge, this_radius, inner_start)
 
 def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, strict=False,
                 return_info=False, out=None, per_scale=False, knn_min=0, knn_radius_factor=3.0,
-                cov_out=None):
+                cov_out=None, normal_out=None):
     """process_single_core for clouds resident in HBM: torch GPU tensors in, (Nq, 4*S) fp64 GPU tensor
     out.  nothing crosses PCIe except six doubles (the search cloud's extrema) and, when strict or
     return_info, 4 counters per scale.
@@ -130,7 +130,8 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
     features from the knn_min nearest voxels within knn_radius_factor * radius.
     cov_out, a (Nq, 6*S) fp64 GPU tensor, additionally receives per scale the upper triangle
     [xx, xy, xz, yy, yz, zz] of the neighborhood covariance whose eigenvalues the features are
-    (see process_gpu_covariance)."""
+    (see process_gpu_covariance).  normal_out, (Nq, 3*S), receives the unit
+    eigenvector of its smallest eigenvalue - the surface normal, pointing up (process_gpu_normals)."""
     assert len(edge_lengths) == len(radii), \
         "edge_lengths and radii should be equal-length sequences."
     shared = query_cloud is search_cloud
@@ -153,16 +154,24 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
                 cov_out.device == out.device and cov_out.ndim == 2 and cov_out.shape[0] == nq and
                 cov_out.shape[1] >= 6 * n_scales and cov_out.stride(1) == 1):
             raise ValueError("cov_out must be a (Nq, >= 6*S) fp64 tensor on the clouds' device")
+    if normal_out is not None:
+        if not (isinstance(normal_out, torch.Tensor) and normal_out.dtype == torch.float64 and
+                normal_out.device == out.device and normal_out.ndim == 2 and normal_out.shape[0] == nq
+                and normal_out.shape[1] >= 3 * n_scales and normal_out.stride(1) == 1):
+            raise ValueError("normal_out must be a (Nq, >= 3*S) fp64 tensor on the clouds' device")
     outer_start = time.perf_counter()
     lo, hi = _device.cloud_bounds(rt, search)
     rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
 
     def covariance_columns(first_scale):
         # context state of the C ABI, like the fallback switch: set for this call, cleared after it
-        if cov_out is None:
-            return
-        rt.check(rt.lib.nm_set_covariance_output(
-            rt.ctx, ctypes.c_void_p(cov_out.data_ptr() + 48 * first_scale), int(cov_out.stride(0))))
+        if cov_out is not None:
+            rt.check(rt.lib.nm_set_covariance_output(
+                rt.ctx, ctypes.c_void_p(cov_out.data_ptr() + 48 * first_scale), int(cov_out.stride(0))))
+        if normal_out is not None:
+            rt.check(rt.lib.nm_set_normal_output(
+                rt.ctx, ctypes.c_void_p(normal_out.data_ptr() + 24 * first_scale),
+                int(normal_out.stride(0))))
 
     try:
         if not (verbose or per_scale):
@@ -181,6 +190,8 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
     finally:
         if cov_out is not None:
             rt.check(rt.lib.nm_set_covariance_output(rt.ctx, None, 0))
+        if normal_out is not None:
+            rt.check(rt.lib.nm_set_normal_output(rt.ctx, None, 0))
     if verbose:
         torch.cuda.synchronize(rt.device)
         outer = time.perf_counter() - outer_start
@@ -214,6 +225,17 @@ def process_gpu_covariance(query_cloud, search_cloud, edge_lengths, radii, **kwa
     cov = torch.zeros((nq, 6 * len(edge_lengths)), dtype=torch.float64, device=rt.device)
     feats = process_gpu(query_cloud, search_cloud, edge_lengths, radii, cov_out=cov, **kwargs)
     return feats, cov
+
+
+def process_gpu_normals(query_cloud, search_cloud, edge_lengths, radii, **kwargs):
+    """(features (Nq, 4*S), normals (Nq, 3*S)): per scale the unit eigenvector of the smallest eigenvalue
+    of the neighborhood covariance, last non-zero component (x, y, z order) positive; zeros where fewer
+    than 3 voxels."""
+    rt, search = _device.as_cloud(search_cloud)
+    nq = search.shape[0] if query_cloud is search_cloud else _device.as_cloud(query_cloud, rt.device)[1].shape[0]
+    normals = torch.zeros((nq, 3 * len(edge_lengths)), dtype=torch.float64, device=rt.device)
+    feats = process_gpu(query_cloud, search_cloud, edge_lengths, radii, normal_out=normals, **kwargs)
+    return feats, normals
 
 
 def one_scale_gpu(query_cloud, search_cloud, edge_length, radius, verbose=False, strict=False):

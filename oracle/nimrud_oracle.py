@@ -238,6 +238,30 @@ def one_scale_covariance(query_cloud, search_cloud, edge_length, radius):
     return out
 
 
+def one_scale_normals(query_cloud, search_cloud, edge_length, radius):
+    """(Nq,3) unit eigenvector of the smallest eigenvalue of numpy.cov(neighborhood) (numpy.linalg.eigh),
+    last non-zero component in x, y, z order made positive; zeros below 3 voxels.  also returns (Nq,)
+    the gap (l2 - l3) / (l1 + l2 + l3): where it is tiny the direction is not defined by the data."""
+    query_xyz = np.asarray(query_cloud, dtype=np.float64)[:, :3]
+    search_xyz = np.asarray(search_cloud, dtype=np.float64)[:, :3]
+    lattice = Lattice(search_xyz, edge_length)
+    voxels = lattice.unique_voxels(search_xyz)
+    nbrs = ball_neighbors_kdtree(query_xyz, voxels, radius)
+    out = np.zeros((len(query_xyz), 3))
+    gap = np.zeros(len(query_xyz))
+    for i, idx in enumerate(nbrs):
+        if len(idx) < 3:
+            continue
+        w, v = np.linalg.eigh(np.cov(voxels.take(idx, axis=0), rowvar=False))
+        n = v[:, 0]
+        nz = np.flatnonzero(np.abs(n) > 0)
+        if len(nz) and n[nz[-1]] < 0:
+            n = -n
+        out[i] = n
+        gap[i] = (w[1] - w[0]) / w.sum() if w.sum() > 0 else 0.0
+    return out, gap
+
+
 def process(query_cloud, search_cloud, edge_lengths, radii, strict=False):
     """(Nq, 4*S): per-scale blocks concatenated column-wise in caller order (multiscale.py:27-67)"""
     assert len(edge_lengths) == len(radii), \

@@ -482,6 +482,44 @@ def test_covariance_output_against_numpy_cov():
     assert torch.equal(multiscale.process_gpu(dev, dev, edges, radii), feats)
 
 
+def test_normal_output_against_numpy_eigh():
+    """nm_set_normal_output: the eigenvector of the smallest covariance eigenvalue (plane normal), sign
+    convention included, against numpy.linalg.eigh on the oracle's neighborhoods wherever the data
+    define it (relative gap between the two smallest eigenvalues above 1e-3); always a unit vector,
+    always an eigenvector of the covariance the library itself reports."""
+    pts, _ = synth.scene_cloud(2500, extent=6.0, n_poles=4, n_spheres=2, seed=828)
+    edges, radii = [0.10, 0.20, 0.1], [0.30, 0.60, 0.55]
+    dev = torch.from_numpy(pts).cuda()
+    cov = torch.zeros((len(pts), 6 * len(edges)), dtype=torch.float64, device="cuda")
+    feats, normals = multiscale.process_gpu_normals(dev, dev, edges, radii, cov_out=cov)
+    f2, n2 = multiscale.process_gpu_normals(dev, dev, edges, radii, per_scale=True)
+    assert torch.equal(normals, n2) and torch.equal(feats, f2)
+    got, f, c = normals.cpu().numpy(), feats.cpu().numpy(), cov.cpu().numpy()
+    for s, (e, r) in enumerate(zip(edges, radii)):
+        want, gap = oracle.one_scale_normals(pts, pts, e, r)
+        v = got[:, 3 * s:3 * s + 3]
+        few = f[:, 4 * s] < 3
+        assert np.all(v[few] == 0.0)
+        assert np.abs(np.linalg.norm(v[~few], axis=1) - 1.0).max() < 1e-12
+        clear = ~few & (gap > 1e-3)
+        assert clear.sum() > 1000
+        # the direction, and the sign wherever the deciding (z) component is not rounding noise
+        d = np.minimum(np.abs(v[clear] - want[clear]).max(axis=1), np.abs(v[clear] + want[clear]).max(axis=1))
+        assert d.max() < 1e-6
+        up = clear & (np.abs(want[:, 2]) > 1e-6)
+        assert up.sum() > 500 and np.all(v[up, 2] > 0) and np.abs(v[up] - want[up]).max() < 1e-6
+        # an eigenvector of the reported covariance with the smallest eigenvalue
+        m = np.zeros((len(v), 3, 3))
+        iu = np.triu_indices(3)
+        m[:, iu[0], iu[1]] = c[:, 6 * s:6 * s + 6]
+        m[:, iu[1], iu[0]] = c[:, 6 * s:6 * s + 6]
+        w = np.linalg.eigvalsh(m)
+        resid = np.einsum("nij,nj->ni", m, v) - w[:, :1] * v
+        scale = np.abs(m).max(axis=(1, 2))
+        ok = ~few & (scale > 0)
+        assert (np.abs(resid[ok]).max(axis=1) / scale[ok]).max() < 1e-9
+
+
 def test_pipelined_ladder_is_bit_identical():
     """nm_set_overlap(1): the indexes are built on the library's auxiliary stream while the caller's
     stream runs the search kernels.  same bits, same counters."""
