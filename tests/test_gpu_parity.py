@@ -651,6 +651,24 @@ def test_knn_fallback_against_oracle(per_scale):
     assert_features_close(off, plain, pts)
 
 
+def test_knn_fallback_behind_the_generic_kernel():
+    """r/e = 5.5 takes the generic search kernel, which does not write the sparse bits itself (k_knn_mark
+    does): same contract, smaller cloud (the oracle's kNN is a cKDTree.query per sparse row)."""
+    rs = np.random.RandomState(133)
+    core = synth.uniform_cloud(6000, extent=2.0, seed=134)
+    sparse = rs.rand(600, 3) * 8.0 - 3.0
+    pts = np.concatenate((core, sparse), axis=0)
+    e, r, k = 0.1, 0.55, 10
+    dev = torch.from_numpy(pts).cuda()
+    got = multiscale.process_gpu(dev, dev, [e], [r], knn_min=k, knn_radius_factor=2.0).cpu().numpy()
+    want = oracle.one_scale_knn(pts, pts, e, r, k, radius_factor=2.0)
+    plain = oracle.one_scale_fast(pts, pts, e, r)
+    touched = plain[:, 0] < k
+    assert touched.sum() > 100
+    assert np.array_equal(got[:, 0], want[:, 0])
+    assert_features_close(got, want, pts)
+
+
 def test_descriptors():
     pts, _ = synth.scene_cloud(20000, extent=8.0, n_poles=5, n_spheres=2, seed=141)
     feats = multiscale.process_single_core(pts, pts, [0.1, 0.2], [0.3, 0.6])
