@@ -26,6 +26,9 @@
 constexpr int ROWS_CAP = 512;   // staged (y,z) rows per wave, 8 B each
 constexpr int SBT_CAP = 192;    // superblock slots of the staged box (3 in x)
 constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anchor lane
+#ifndef NM_CENTRE_TABLE
+#define NM_CENTRE_TABLE 1
+#endif
 constexpr int NM_BOX_EX = 62;   // x extent of a staged box: 64-bit rows, kept shifted left by two
 
 struct ScaleArgs {
@@ -601,10 +604,29 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         }
     }
 
+    // the wave's box of home cells (it is also the first pass's box).  when it is at most 64 cells wide
+    // on every axis - nearly always - each voxel centre the wave will need is computed ONCE, by one lane,
+    // into a table in LDS (bit-identical: same expression), instead of 3 W times by every lane
+    int32_t blox = done ? INT32_MAX : hx, bhix = done ? INT32_MIN : hx;
+    int32_t bloy = done ? INT32_MAX : hy, bhiy = done ? INT32_MIN : hy;
+    int32_t bloz = done ? INT32_MAX : hz, bhiz = done ? INT32_MIN : hz;
+    wave_bbox(blox, bhix, bloy, bhiy, bloz, bhiz);
+    const bool tab = NM_CENTRE_TABLE && blox <= bhix && (int64_t)bhix - blox + W <= 64 &&
+                     (int64_t)bhiy - bloy + W <= 64 && (int64_t)bhiz - bloz + W <= 64;
+    double* ctab = (double*)rows;      // 3 x 64 doubles; the row buffer is not in use yet
+    if (tab) {
+        ctab[lane] = nm_centre(blox + dmin + lane, L.min_x, L.edge, L.half_edge);
+        ctab[64 + lane] = nm_centre(bloy + dmin + lane, L.min_y, L.edge, L.half_edge);
+        ctab[128 + lane] = nm_centre(bloz + dmin + lane, L.min_z, L.edge, L.half_edge);
+    }
+    lds_fence();
+    // table positions of this lane's window (lanes that are done read somewhere harmless)
+    const int32_t tx = done ? 0 : hx - blox, ty = done ? C : hy - bloy + C, tz = done ? C : hz - bloz + C;
+
     // reflect the window in y and z so that the query is in the upper half of its home cell there
     // (population, centroid distance and eigenvalues are invariant under these reflections)
-    const double uy_home = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
-    const double uz_home = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
+    const double uy_home = qy - (tab ? ctab[64 + ty] : nm_centre(hy, L.min_y, L.edge, L.half_edge));
+    const double uz_home = qz - (tab ? ctab[128 + tz] : nm_centre(hz, L.min_z, L.edge, L.half_edge));
     const int32_t sgn_y = uy_home < 0.0 ? -1 : 1;
     const int32_t sgn_z = uz_home < 0.0 ? -1 : 1;
 
@@ -615,14 +637,29 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         // squared coordinate differences to the W candidate centres per axis (bit-identical centres)
         // index i of the y and z tables is in the lane's mirrored frame: cell = home + sgn*(i - C)
         double dx2[W], dy2[W], dz2[W];
+        if (tab) {
+            const double* cx = ctab + tx;
+            const double* cy = ctab + 64 + ty;
+            const double* cz = ctab + 128 + tz;
 #pragma unroll
-        for (int i = 0; i < W; ++i) {
-            double d = qx - nm_centre(hx + dmin + i, L.min_x, L.edge, L.half_edge);
-            dx2[i] = d * d;
-            d = qy - nm_centre(hy + sgn_y * (i - C), L.min_y, L.edge, L.half_edge);
-            dy2[i] = d * d;
-            d = qz - nm_centre(hz + sgn_z * (i - C), L.min_z, L.edge, L.half_edge);
-            dz2[i] = d * d;
+            for (int i = 0; i < W; ++i) {
+                double d = qx - cx[i];
+                dx2[i] = d * d;
+                d = qy - cy[sgn_y * (i - C)];
+                dy2[i] = d * d;
+                d = qz - cz[sgn_z * (i - C)];
+                dz2[i] = d * d;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                double d = qx - nm_centre(hx + dmin + i, L.min_x, L.edge, L.half_edge);
+                dx2[i] = d * d;
+                d = qy - nm_centre(hy + sgn_y * (i - C), L.min_y, L.edge, L.half_edge);
+                dy2[i] = d * d;
+                d = qz - nm_centre(hz + sgn_z * (i - C), L.min_z, L.edge, L.half_edge);
+                dz2[i] = d * d;
+            }
         }
 #pragma unroll
         for (int r = 0; r < MASK_REGS; ++r) inside[r] = 0u;
@@ -671,10 +708,13 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         ++passes;
         // ---- choose the box: bounding box of the pending lanes if it fits, else a fixed box around
         //      the first pending lane
-        int32_t lox = done ? INT32_MAX : hx, hix = done ? INT32_MIN : hx;
-        int32_t loy = done ? INT32_MAX : hy, hiy = done ? INT32_MIN : hy;
-        int32_t loz = done ? INT32_MAX : hz, hiz = done ? INT32_MIN : hz;
-        wave_bbox(lox, hix, loy, hiy, loz, hiz);
+        int32_t lox = blox, hix = bhix, loy = bloy, hiy = bhiy, loz = bloz, hiz = bhiz;
+        if (passes > 1) {      // the first pass's box is the wave's box, already known
+            lox = done ? INT32_MAX : hx; hix = done ? INT32_MIN : hx;
+            loy = done ? INT32_MAX : hy; hiy = done ? INT32_MIN : hy;
+            loz = done ? INT32_MAX : hz; hiz = done ? INT32_MIN : hz;
+            wave_bbox(lox, hix, loy, hiy, loz, hiz);
+        }
         int64_t ex64 = (int64_t)hix - lox + W, ey64 = (int64_t)hiy - loy + W,
                 ez64 = (int64_t)hiz - loz + W;
         int32_t ox = lox + dmin, oy = loy + dmin, oz = loz + dmin;
