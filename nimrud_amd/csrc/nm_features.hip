@@ -671,14 +671,15 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
 #pragma unroll
             for (int k = 0; k < W; ++k) {
                 const RowBound rb = RHO3 ? NM_BOUNDS_RHO3.rb[j * W + k] : RT.rb[j * W + k];
-                // "outside" bits, candidate i in bit i; candidates that are never inside start as 1
+                // "outside" bits of the candidates C-b .. C+b (the ones further out are never inside: their
+                // bits of the row mask simply stay clear), candidate C-b in bit 0
+                if (rb.b < 0) continue;
                 uint32_t outside = 0u;
 #pragma unroll
                 for (int i = W - 1; i >= 0; --i) {
                     const int ad = i > C ? i - C : C - i;
-                    if (ad > rb.b) {
-                        outside = (outside << 1) | 1u;
-                    } else if (ad <= rb.a) {
+                    if (ad > rb.b) continue;
+                    if (ad <= rb.a) {
                         outside = outside << 1;
                     } else {
                         const double s = pxy[i] + dz2[k];
@@ -686,9 +687,10 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                         outside = __builtin_amdgcn_alignbit(outside, (uint32_t)__double2hiint(t), 31);
                     }
                 }
-                constexpr uint32_t FULL = (1u << W) - 1u;
+                const uint32_t span = (1u << (2 * rb.b + 1)) - 1u;
                 const int row = j * W + k;
-                inside[row / ROWS_PER_REG] |= ((~outside) & FULL) << ((row % ROWS_PER_REG) * W + 2);
+                inside[row / ROWS_PER_REG] |= ((~outside) & span)
+                                              << ((row % ROWS_PER_REG) * W + 2 + (C - rb.b));
             }
             // keep the rows of different j apart: without this the scheduler interleaves all W*W
             // chains and the live set (W*W partial sums) costs two waves of occupancy
