@@ -46,3 +46,23 @@ for trial in range(8):
           % (trial, w.data_ptr() % (2 << 20), out.data_ptr() % (2 << 20), k, i, o), flush=True)
     del out
 
+
+# the workspace carved out of one big allocation at different 2 MiB-aligned offsets (same physical pool):
+# which address bit, if any, decides?
+rt.release_workspace()
+del keep
+torch.cuda.empty_cache()
+need = rt.lib.nm_multiscale_workspace_bytes  # sized through a dry run of process_gpu below
+out = torch.empty((n, 20), dtype=torch.float64, device="cuda")
+multiscale.process_gpu(dev, dev, edges, radii, out=out)
+wbytes = rt._work.numel()
+rt.release_workspace()
+torch.cuda.empty_cache()
+pool = torch.empty(wbytes + (2 << 30), dtype=torch.uint8, device="cuda")
+base = pool.data_ptr()
+for off in (0, 2 << 20, 4 << 20, 8 << 20, 16 << 20, 32 << 20, 64 << 20, 128 << 20, 256 << 20, 512 << 20,
+            1 << 30, (1 << 30) + (2 << 20), 3 << 29):
+    rt._work = pool[off:off + wbytes]
+    k, i, o = kernel_ms(out)
+    print("workspace at pool + %10d (address bits 21..31 = %s): kernels %.3f ms, index %.3f"
+          % (off, format(((base + off) >> 21) & 0x7FF, "011b"), k, i), flush=True)
