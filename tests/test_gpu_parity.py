@@ -520,6 +520,27 @@ def test_normal_output_against_numpy_eigh():
         assert (np.abs(resid[ok]).max(axis=1) / scale[ok]).max() < 1e-9
 
 
+def test_ladder_argument_checks():
+    """the C ABI refuses what it cannot do, with the reference's exception type where there is one."""
+    pts = synth.uniform_cloud(3000, extent=2.0, seed=909)
+    dev = torch.from_numpy(pts).cuda()
+    with pytest.raises(AssertionError):                       # multiscale.py:32
+        multiscale.process_gpu(dev, dev, [0.1, 0.2], [0.3])
+    with pytest.raises(ValueError):                           # more scales than one call takes
+        multiscale.process_gpu(dev, dev, [0.1] * 33, [0.3] * 33)
+    with pytest.raises(ValueError):                           # 64 address bits are not enough
+        multiscale.process_gpu(dev, dev, [1e-9], [3e-9])
+    with pytest.raises(ValueError):
+        multiscale.process_gpu(dev, dev, [0.1], [0.3], cov_out=torch.zeros((3000, 5), dtype=torch.float64,
+                                                                           device="cuda"))
+    with pytest.raises(ValueError):
+        multiscale.process_gpu(dev, dev, [0.1], [0.3], normal_out=torch.zeros((3000, 3), dtype=torch.float32,
+                                                                              device="cuda"))
+    # and the library is still usable afterwards
+    got = multiscale.process_gpu(dev, dev, [0.1], [0.3]).cpu().numpy()
+    assert_features_close(got, oracle.process_fast(pts, pts, [0.1], [0.3]), pts)
+
+
 def test_pipelined_ladder_is_bit_identical():
     """nm_set_overlap(1): the indexes are built on the library's auxiliary stream while the caller's
     stream runs the search kernels.  same bits, same counters."""
