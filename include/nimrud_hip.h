@@ -226,6 +226,22 @@ int nm_copy_xyz(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, dou
 int nm_descriptors(nm_ctx* ctx, const double* d_feat, int64_t n, int32_t n_scales, int64_t feat_stride,
                    double* d_out, int64_t out_stride, void* stream);
 
+/* ---- vector-field operator (legacy V_MSO, prototypes/mso.py:12-173) ----------
+ * neighborhood mean of arbitrary per-point attributes on the lattice of nimrud/minimal: the search cloud
+ * is voxel-filtered as for the features (geometry.py:103-154); a voxel's attribute vector is the mean of
+ * d_attr[row*attr_stride + 0..dims) over the search points in it; query row q receives, in
+ * d_out[q*out_stride + 0..dims), the mean of the voxel attributes over the voxel centres within
+ * `radius` (inclusive, the predicate of multiscale.py:87-103), zeros if there are none.  1 <= dims <= 16.
+ * one scale per call.  the legacy operator (fp32, partition dependent) cannot be reproduced number for
+ * number and the reference's current path has none: parity is pinned by the build's own oracle.      */
+size_t nm_field_workspace_bytes(int64_t n_query, int64_t n_search, const nm_lattice* lat, int32_t dims);
+int nm_field_mean(nm_ctx* ctx,
+                  const double* d_query, int64_t n_query, int64_t query_stride,
+                  const double* d_search, int64_t n_search, int64_t search_stride,
+                  const double* d_attr, int64_t attr_stride, int32_t dims,
+                  const nm_lattice* lat, double radius,
+                  double* d_out, int64_t out_stride, void* d_work, size_t work_bytes, void* stream);
+
 /* ---- classifier slot -------------------------------------------------------------------------------
  * nimrud/minimal/classification.py is a stub; the reference's classifier is sklearn's
  * RandomForestClassifier (prototypes/apc.py:1463) applied per point with predict / predict_proba

@@ -262,6 +262,29 @@ def one_scale_normals(query_cloud, search_cloud, edge_length, radius):
     return out, gap
 
 
+def one_scale_field_mean(query_cloud, search_cloud, attributes, edge_length, radius):
+    """(Nq, D): mean over the voxels within `radius` of each query point of the voxel attribute, a voxel's
+    attribute being the mean of `attributes` over the search points in it; zeros where no voxel is in
+    reach.  the definition of nimrud_amd.minimal.fields (legacy V_MSO,
+    prototypes/mso.py:12-173, is fp32 and partition dependent and cannot serve as a pin)."""
+    query_xyz = np.asarray(query_cloud, dtype=np.float64)[:, :3]
+    search_xyz = np.asarray(search_cloud, dtype=np.float64)[:, :3]
+    attr = np.asarray(attributes, dtype=np.float64).reshape(len(search_xyz), -1)
+    lattice = Lattice(search_xyz, edge_length)
+    addresses = lattice.coordinate_to_address(search_xyz)
+    unique, inverse = np.unique(addresses, return_inverse=True)
+    counts = np.bincount(inverse, minlength=len(unique)).astype(np.float64)
+    vmean = np.stack([np.bincount(inverse, weights=attr[:, d], minlength=len(unique)) / counts
+                      for d in range(attr.shape[1])], axis=1)
+    voxels = lattice.address_to_coordinate(unique)
+    nbrs = ball_neighbors_kdtree(query_xyz, voxels, radius)
+    out = np.zeros((len(query_xyz), attr.shape[1]))
+    for i, idx in enumerate(nbrs):
+        if len(idx):
+            out[i] = vmean.take(idx, axis=0).mean(axis=0)
+    return out
+
+
 def process(query_cloud, search_cloud, edge_lengths, radii, strict=False):
     """(Nq, 4*S): per-scale blocks concatenated column-wise in caller order (multiscale.py:27-67)"""
     assert len(edge_lengths) == len(radii), \

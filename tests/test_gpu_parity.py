@@ -14,7 +14,7 @@ import torch
 
 from conftest import assert_features_close
 from nimrud_amd import synth
-from nimrud_amd.minimal import classification, features, multiscale
+from nimrud_amd.minimal import classification, features, fields, multiscale
 from nimrud_amd.utils import geometry
 from oracle import nimrud_oracle as oracle
 
@@ -518,6 +518,35 @@ def test_normal_output_against_numpy_eigh():
         scale = np.abs(m).max(axis=(1, 2))
         ok = ~few & (scale > 0)
         assert (np.abs(resid[ok]).max(axis=1) / scale[ok]).max() < 1e-9
+
+
+def test_vector_field_mean_against_oracle():
+    """nm_field_mean: neighborhood means of per-point attributes over the same voxels
+    and the same ball as the features; a constant field comes back constant, a coordinate field comes
+    back as the neighborhood's voxel-weighted centre."""
+    rs = np.random.RandomState(939)
+    pts, labels = synth.scene_cloud(6000, extent=8.0, n_poles=5, n_spheres=2, seed=938)
+    query = np.concatenate((pts[:1500], rs.rand(300, 3) * 10.0 - 1.0))
+    attr = np.stack([np.sin(pts[:, 0]), pts[:, 2] ** 2, labels.astype(np.float64),
+                     np.full(len(pts), 3.25), rs.rand(len(pts))], axis=1)
+    edges, radii = [0.1, 0.25], [0.3, 1.2]
+    got = fields.vector_field_mean(query, pts, attr, edges, radii)
+    assert got.shape == (len(query), 10)
+    for s, (e, r) in enumerate(zip(edges, radii)):
+        want = oracle.one_scale_field_mean(query, pts, attr, e, r)
+        assert np.abs(got[:, 5 * s:5 * s + 5] - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+        pop = oracle.one_scale_fast(query, pts, e, r)[:, 0]
+        const = got[:, 5 * s + 3]
+        assert np.all(const[pop == 0] == 0.0) and np.abs(const[pop > 0] - 3.25).max() < 1e-12
+    # one column, given as a vector; query = search on the device
+    dev = torch.from_numpy(pts).cuda()
+    one = fields.vector_field_mean_gpu(dev, dev, torch.from_numpy(attr[:, 1]).cuda(), [0.1], [0.3])
+    assert one.shape == (len(pts), 1)
+    assert np.abs(one.cpu().numpy()[:, 0] - oracle.one_scale_field_mean(pts, pts, attr[:, 1], 0.1, 0.3)[:, 0]).max() < 1e-11
+    with pytest.raises(ValueError):
+        fields.vector_field_mean(query, pts, np.zeros((len(pts), 17)), [0.1], [0.3])
+    with pytest.raises(ValueError):
+        fields.vector_field_mean(query, pts, attr[:-1], [0.1], [0.3])
 
 
 def test_ladder_argument_checks():
