@@ -88,14 +88,19 @@ __global__ __launch_bounds__(256) void k_field_voxel_mean(const uint32_t* __rest
 
 // one lane per query: every occupied candidate cell inside the radius contributes its voxel's attribute
 __global__ __launch_bounds__(64) void k_field_query(const double* __restrict__ query, int64_t nq,
-                                                    int64_t qstride, LatticeDev L, IndexDev I,
+                                                    int64_t qstride,
+                                                    const uint32_t* __restrict__ order,   // nullable
+                                                    LatticeDev L, IndexDev I,
                                                     const uint32_t* __restrict__ rowbase,
                                                     const double* __restrict__ vmean, int32_t dims,
                                                     double r2, int32_t dmin, int32_t W,
                                                     double* __restrict__ out, int64_t ostride)
 {
-    const int64_t qi = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (qi >= nq) return;
+    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (slot >= nq) return;
+    // in the spatial order of the sort when the queries are the search points themselves: the lanes of
+    // a wave then walk the same leaves
+    const int64_t qi = order ? (int64_t)order[slot] : slot;
     const double* p = query + qi * qstride;
     const double qx = p[0], qy = p[1], qz = p[2];
     const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
@@ -250,7 +255,11 @@ extern "C" int nm_field_mean(nm_ctx* ctx, const double* d_query, int64_t n_query
     k_field_voxel_mean<<<blocks < 4096 ? blocks : 4096, 256, 0, s>>>(start, row_of, n_voxels, d_attr,
                                                                      attr_stride, dims, vmean);
     if (n_query > 0)
-        k_field_query<<<(int)((n_query + 63) / 64), 64, 0, s>>>(d_query, n_query, query_stride, L, I,
+        k_field_query<<<(int)((n_query + 63) / 64), 64, 0, s>>>(d_query, n_query, query_stride,
+                                                               (d_query == d_search && n_query == n_search &&
+                                                                query_stride == search_stride)
+                                                                   ? row_of : nullptr,
+                                                               L, I,
                                                                rowbase, vmean, dims, radius * radius,
                                                                dmin, W, d_out, out_stride);
     NM_HIP(ctx, hipGetLastError());
