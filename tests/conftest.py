@@ -34,7 +34,7 @@ def golden():
 #   themselves: the reference forms every voxel centre in world coordinates (up to 2 ulp of the
 #   coordinate each: cell*e, + min_corner, + e/2), sums k of them (numpy.mean) and subtracts; at
 #   UTM-scale offsets its own value therefore carries tens of ulp(|coordinate|) of noise, while the GPU
-#   path works in exact integer offsets from the home voxel.  a randomised sweep (tools/fuzz_parity.py)
+#   path works in exact integer offsets from the home voxel.  a randomised sweep (tests/fuzz_parity.py)
 #   saw differences up to 20 ulp; 64 ulp are allowed.
 def assert_features_close(got, want, points, eig_rtol=1e-5, eig_atol=1e-9):
     got = np.asarray(got)

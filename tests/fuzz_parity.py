@@ -1,8 +1,9 @@
 """randomised parity sweep: GPU (through the C ABI) against the oracle on many small random cases.
-not part of the test suite (minutes of oracle time); run on the GPU box:  python tools/fuzz_parity.py 200"""
+a parity checker like the tests next to it, but not collected by pytest (minutes of oracle time);
+run on the GPU box:  python tests/fuzz_parity.py 200 [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from nimrud_amd import synth
 from nimrud_amd.minimal import multiscale
