@@ -7,13 +7,13 @@ REV=$1; NAME=$2; shift 2
 R=$(cd "$(dirname "$0")/.." && pwd)
 D=$R/build_abl/$NAME
 rm -rf "$D"; mkdir -p "$D/nimrud_amd/csrc" "$D/include"
-for f in nm_api.hip nm_index.hip nm_features.hip nm_halo.hip nm_common.h nm_index.h; do
-  git -C "$R" show "$REV:nimrud_amd/csrc/$f" > "$D/nimrud_amd/csrc/$f"
+for f in $(git -C "$R" ls-tree --name-only "$REV" nimrud_amd/csrc/ | grep -E '\.(hip|h)$'); do
+  git -C "$R" show "$REV:$f" > "$D/$f"
 done
 git -C "$R" show "$REV:include/nimrud_hip.h" > "$D/include/nimrud_hip.h"
 cd "$D/nimrud_amd/csrc"
-for f in nm_api nm_index nm_features nm_halo; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math "$@" -c $f.hip -o $f.o &
+for f in *.hip; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math "$@" -c $f -o ${f%.hip}.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/build_abl/lib_$NAME.so" *.o
