@@ -7,10 +7,15 @@ dominant kernel and the reference CPU path timed beside it.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 a "step" is one pass of the hot path over one batch of synthetic input: all scales of
-process_single_core's scale loop (cell keys -> sort -> occupancy index -> fused search/moments/eigen
-kernel, per scale) over a cloud that is already resident in HBM.  with N > 1 every rank owns one
-Morton-contiguous spatial tile of the same size (weak scaling) and a step begins with the halo
-exchange over RCCL.  rank 0 prints ONE JSON line.
+process_single_core's scale loop (spatial order -> occupancy indexes -> fused search/moments/eigen
+kernel per scale) over a cloud that is already resident in HBM.
+
+N > 1, --scaling strong (default; BASELINE config 3 as stated): ONE 10 M-point Morton-ordered cloud is
+cut into N Morton-contiguous tiles, one per rank; a step begins with the halo exchange over RCCL
+(nm_halo_exchange: cell-set halos) and `value` counts the 10 M points once.  --scaling weak: every rank
+owns its own 10 M-point scene, the scenes abut along x.  N = 1 is the same workload either way.
+--workload c5_scene_10m_rf adds the per-point random-forest evaluation (BASELINE config 5) and reports
+classified points/s end to end.  rank 0 prints ONE JSON line.
 """
 
 import argparse
@@ -25,25 +30,63 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join(REPO, "profiles", "r1_final_traffic.json")
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak
+PROFILE_ROUND = "r2"
 
 
-def measured_traffic(points_per_gpu):
+def _profile_json(name):
+    for rnd in (PROFILE_ROUND, "r1_final"):
+        path = os.path.join(REPO, "profiles", "%s_%s.json" % (rnd, name))
+        if os.path.exists(path):
+            try:
+                return json.load(open(path)), os.path.relpath(path, REPO)
+            except Exception:   # noqa: BLE001
+                pass
+    return None, None
+
+
+def measured_traffic(points_per_gpu, kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (tools/pmc_summary.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
-    doubled as the gfx950 note in MI355X_MICROARCH.md prescribes and as calibrated on k_cell_keys_only).
-    only valid for the configuration it was collected on; None otherwise."""
-    if points_per_gpu != 10_000_000 or not os.path.exists(TRAFFIC_FILE):
+    doubled as the gfx950 note in MI355X_MICROARCH.md prescribes).  only valid for the configuration it
+    was collected on; None otherwise."""
+    data, path = _profile_json("traffic")
+    if points_per_gpu != 10_000_000 or data is None:
+        return None, None
+    for name, rec in data.get("kernels", {}).items():
+        if name.startswith(kernel_prefix):
+            return rec.get("hbm_bytes_per_launch_mean"), path
+    return None, None
+
+
+def valu_ceiling(n_queries, kernel_ms):
+    """the second roofline SURVEY 8d asks for: the ALU candidate-test ceiling.  from the committed SQ
+    counters of the dominant kernel (instructions per wave by class, mean over the five scales of the
+    step; tools/collect_profiles.sh) and the live query rate: fp64 flop per query x queries/s against
+    the fp64 vector peak, next to how full the vector-ALU issue slots are."""
+    data, path = _profile_json("instruction_mix")
+    if data is None or "per_wave" not in data:
         return None
     try:
-        data = json.load(open(TRAFFIC_FILE))
-        for name, rec in data["kernels"].items():
-            if name.startswith("k_scale_features<7"):
-                return rec.get("hbm_bytes_per_launch_mean")
+        pw = {k: float(np.mean(v)) for k, v in data["per_wave"].items()}
+        flop = (pw["SQ_INSTS_VALU_ADD_F64"] + pw["SQ_INSTS_VALU_MUL_F64"] +
+                2.0 * pw["SQ_INSTS_VALU_FMA_F64"] + pw["SQ_INSTS_VALU_TRANS_F64"])
+        queries_per_s = n_queries / (kernel_ms * 1e-3)
+        tflops = flop * queries_per_s / 1e12       # one lane of a wave instruction = one query's flop
+        # issue slots: SQ_ACTIVE_INST_VALU counts quad-cycles per wave; 1024 SIMDs at the 2.4 GHz
+        # maximum clock (the clock held under load is lower, so this fraction is a lower bound)
+        simd_cycles = kernel_ms * 1e-3 * 2.4e9 * 1024
+        busy = (n_queries / 64.0) * pw["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
+        return {"bound": "valu-issue", "valu_instr_per_wave": pw["SQ_INSTS_VALU"],
+                "fp64_instr_per_wave": flop - pw["SQ_INSTS_VALU_FMA_F64"],
+                "fp64_flop_per_query": flop,
+                "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                "valu_issue_busy_frac": busy,
+                "source": path}
     except Exception:   # noqa: BLE001
         return None
-    return None
 
 
 def parse_args():
@@ -52,12 +95,22 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3_scene_10m")
-    ap.add_argument("--points", type=int, default=None, help="points per GPU (default: the config's)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = one cloud cut into N Morton tiles, weak = one cloud per rank")
+    ap.add_argument("--halo", choices=("cells", "boxes"), default="cells")
+    ap.add_argument("--points", type=int, default=None, help="points of the cloud (default: the config's)")
     ap.add_argument("--overlap", type=int, default=None,
-                    help="nm_set_overlap value (0 = sequential stages, 1 = default pipelining)")
+                    help="nm_set_overlap value (0 = sequential stages, 1 = pipelining)")
     ap.add_argument("--cpu-sample", type=int, default=150000,
                     help="points of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
+
+
+# ---- CPU baselines (rank 0, N = 1; they run BEFORE the process touches the GPU) ---------------------------
+
+def _slice(points, sample):
+    lo = max(0, len(points) // 2 - sample // 2)
+    return np.ascontiguousarray(points[lo:lo + sample])
 
 
 def cpu_baseline(points, edges, radii, sample):
@@ -69,13 +122,12 @@ def cpu_baseline(points, edges, radii, sample):
         limiter = threadpool_limits(limits=1)
     except Exception:   # noqa: BLE001
         limiter = None
-    lo = max(0, len(points) // 2 - sample // 2)
-    tile = np.ascontiguousarray(points[lo:lo + sample])
+    tile = _slice(points, sample)
     t0 = time.perf_counter()
     oracle.process(tile, tile, edges, radii)
     dt = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
+    if limiter is not None and hasattr(limiter, "restore_original_limits"):
+        limiter.restore_original_limits()
     return {
         "value": len(tile) * len(edges) / dt,
         "unit": "point-scales/s",
@@ -96,11 +148,10 @@ def _cpu_chunk(args):
 
 def cpu_baseline_multicore(points, edges, radii, sample, workers):
     """the same restatement over a process pool, 1000-point query chunks per task - the parallelisation
-    the reference itself suggests (nimrud/minimal/multiscale.py:92-93).  every task voxel-filters and
-    indexes the search tile again, exactly what mapping one_scale_single_core over chunks would do."""
+    the reference itself suggests (nimrud/minimal/multiscale.py:92-93).  the pool is forked before this
+    process has initialised HIP."""
     import multiprocessing as mp
-    lo = max(0, len(points) // 2 - sample // 2)
-    tile = np.ascontiguousarray(points[lo:lo + sample])
+    tile = _slice(points, sample)
     step = max(1000, sample // (workers * 4) // 1000 * 1000)
     tasks = [(tile[i:i + step], tile, edges, radii) for i in range(0, len(tile), step)]
     t0 = time.perf_counter()
@@ -117,8 +168,7 @@ def cpu_lattice_c(points, edges, radii, sample):
     occupied voxels, lattice enumeration, OpenMP over queries) on a larger slice of the same cloud."""
     from oracle import nimrud_oracle as oracle
     threads = min(16, os.cpu_count() or 1)
-    lo = max(0, len(points) // 2 - sample // 2)
-    tile = np.ascontiguousarray(points[lo:lo + sample])
+    tile = _slice(points, sample)
     t0 = time.perf_counter()
     oracle.process_c(tile, tile, edges, radii, threads=threads)
     dt = time.perf_counter() - t0
@@ -127,58 +177,125 @@ def cpu_lattice_c(points, edges, radii, sample):
                                       "%d scales, %.1f s" % (len(tile), len(edges), dt)}
 
 
+def cpu_forest(model_arrays, feature_rows):
+    """config 5's classifier stage on one core: the oracle's forest walk (numpy) on a sample of rows."""
+    from oracle import nimrud_oracle as oracle
+    t0 = time.perf_counter()
+    oracle.forest_predict(model_arrays, feature_rows)
+    dt = time.perf_counter() - t0
+    return {"value": len(feature_rows) / dt, "unit": "classified rows/s (forest stage only)", "cores": 1,
+            "kind": "port", "sample": "oracle.forest_predict on %d feature rows, %.1f s"
+                                      % (len(feature_rows), dt)}
+
+
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-    from nimrud_amd import synth, device as nm_device
-    from nimrud_amd.minimal import multiscale
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                          % (args.gpus, world))
-    # one rank per GPU.  NIMRUD_BENCH_BACKEND=gloo lets several ranks share a GPU to rehearse the
-    # multi-rank code path on a one-GPU box (collectives staged through host memory; not a benchmark).
-    backend = os.environ.get("NIMRUD_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    from nimrud_amd import synth
+
+    # ---- synthetic input (host) ------------------------------------------------------------------------
+    cfg = synth.CONFIGS[args.workload]
+    n_cloud = args.points or cfg["n"]
+    classify = bool(cfg.get("forest"))
+    strong = world > 1 and args.scaling == "strong"
+    points, labels, edges, radii = synth.make_config(args.workload, n=n_cloud,
+                                                     seed_offset=0 if strong else rank)
+    n_scales = len(edges)
+    if world > 1 and not strong:
+        # weak scaling: scenes abut along x (ground planes tile seamlessly; spheres and poles near a seam
+        # reach into the neighbour), so every seam carries a real halo
+        extent = cfg.get("extent", 0.0) * (np.sqrt(n_cloud / cfg["n"]) if cfg["kind"] == "scene"
+                                           else (n_cloud / cfg["n"]) ** (1.0 / 3.0))
+        points[:, 0] += rank * float(extent)
+    if strong:
+        # config 3 as stated: ONE Morton-ordered cloud, rank r owns the r-th of N contiguous runs.  (rows
+        # of the config are already in Morton order of the coarsest cell.)
+        cut = [len(points) * r // world for r in range(world + 1)]
+        tile = np.ascontiguousarray(points[cut[rank]:cut[rank + 1]])
+    else:
+        tile = points
+
+    # ---- CPU legs first: nothing below has touched the GPU yet (no fork after HIP is up) --------------
+    cpu = {}
+    forest_arrays = None
+    if classify:
+        fixture = np.load(os.path.join(REPO, "tests", "golden", cfg["forest"]), allow_pickle=False)
+        forest_arrays = {k: fixture[k] for k in ("left", "right", "feature", "threshold", "value",
+                                                 "roots", "classes")}
+        forest_arrays["n_features"] = int(fixture["n_features"])
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        cpu["cpu_baseline"] = cpu_baseline(points, edges, radii, args.cpu_sample)
+        workers = min(32, os.cpu_count() or 1)
+        if workers > 1:
+            try:
+                cpu["cpu_baseline_multicore"] = cpu_baseline_multicore(points, edges, radii,
+                                                                       args.cpu_sample, workers)
+            except Exception as err:   # noqa: BLE001 - a reported extra, never fatal
+                cpu["cpu_baseline_multicore"] = {"error": str(err)[:200]}
+        try:
+            cpu["cpu_lattice_c"] = cpu_lattice_c(points, edges, radii, 2_000_000)
+        except Exception as err:       # noqa: BLE001
+            cpu["cpu_lattice_c"] = {"error": str(err)[:200]}
+        if classify:
+            cpu["cpu_forest"] = cpu_forest(forest_arrays, fixture["x"])
+
+    # ---- GPU ------------------------------------------------------------------------------------------------
+    import torch
+    import torch.distributed as dist
+    from nimrud_amd import device as nm_device
+    from nimrud_amd.minimal import multiscale, classification
+
+    # one rank per GPU.  NIMRUD_BENCH_BACKEND=gloo-shared lets several ranks share a GPU to rehearse the
+    # multi-rank code path on a one-GPU box (collectives over gloo, staged through host memory; not a
+    # benchmark).
+    rehearsal = os.environ.get("NIMRUD_BENCH_BACKEND", "") in ("gloo", "gloo-shared")
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    comm = None
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # torch.distributed is the bootstrap only (the RCCL unique id, the barriers around the timed
+        # region, the max over ranks): gloo is enough.  the data path's communicator belongs to the
+        # library (nm_comm_create) and the exchange is nm_halo_exchange.
+        dist.init_process_group("gloo")
+        from nimrud_amd import parallel
+        if not rehearsal:
+            comm = parallel.RcclComm(rank=rank, world=world, device=dev)
 
-    # ---- synthetic input: one tile per rank, tiles side by side along x ---------------------------
-    cfg = synth.CONFIGS[args.workload]
-    n_points = args.points or cfg["n"]
-    points, _, edges, radii = synth.make_config(args.workload, n=n_points, seed_offset=rank)
-    if world > 1:
-        # tiles abut along x (ground planes tile seamlessly; spheres and poles near a seam reach into
-        # the neighbour), so every seam carries a real halo of width max(radius + 0.87 edge)
-        extent = cfg.get("extent", 0.0) * (np.sqrt(n_points / cfg["n"]) if cfg["kind"] == "scene"
-                                           else (n_points / cfg["n"]) ** (1.0 / 3.0))
-        points[:, 0] += rank * float(extent)
-    cloud = torch.from_numpy(points).to(dev)
-    n_scales = len(edges)
+    cloud = torch.from_numpy(tile).to(dev)
     rt = nm_device.get_runtime(dev)
     if args.overlap is not None:
         rt.check(rt.lib.nm_set_overlap(rt.ctx, args.overlap))
+    model = classification.ForestModel.from_arrays(forest_arrays, device=dev) if classify else None
 
     if world > 1:
-        from nimrud_amd import parallel
-        plan = parallel.TilePlan(cloud, edges, radii)
+        plan = parallel.TilePlan(cloud, edges, radii, comm=comm, halo=args.halo)
 
-        def step():
+        def features_step():
             return parallel.process_tile(plan)
     else:
         out = torch.empty((cloud.shape[0], 4 * n_scales), dtype=torch.float64, device=dev)
 
-        def step():
+        def features_step():
             return multiscale.process_gpu(cloud, cloud, edges, radii, out=out)
+
+    forest_ms = []
+
+    def step():
+        feats = features_step()
+        if model is None:
+            return feats
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _, label, _ = model._eval(feats, False, True)
+        e1.record()
+        forest_ms.append((e0, e1))
+        return label
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -189,6 +306,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    forest_ms.clear()
     rt.lib.nm_profile_begin(rt.ctx)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -199,6 +317,7 @@ def main():
     ms = (ctypes.c_double * 4)()
     launches = ctypes.c_int64(0)
     rt.check(rt.lib.nm_profile_end(rt.ctx, ctypes.byref(ms), ctypes.byref(launches)))
+    rt.check_async(wait=True)
 
     # occupied voxels per scale (for the algorithmic byte count), outside the timed region
     _, info = multiscale.process_gpu(cloud, cloud, edges, radii, return_info=True) \
@@ -207,11 +326,10 @@ def main():
     n_local_search = cloud.shape[0] if world == 1 else plan.search_points()
 
     if world > 1:
-        cdev = dev if backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([cloud.shape[0], plan.halo_received], dtype=torch.int64, device=cdev)
+        tot = torch.tensor([cloud.shape[0], plan.halo_received], dtype=torch.int64)
         dist.all_reduce(tot)
         total_points, total_halo = int(tot[0].item()), int(tot[1].item())
     else:
@@ -234,56 +352,70 @@ def main():
         del src, dst
 
     if rank == 0:
-        point_scales = total_points * n_scales * args.steps
-        value = point_scales / elapsed
+        nq = cloud.shape[0]
         # dominant kernel = k_scale_features<7>: per launch it reads the query coordinates (24 B) and
         # the occupied-voxel set (8 B per voxel as addresses) and writes 4 fp64 features (32 B).
-        nq = cloud.shape[0]
         alg_bytes = float(np.mean([56.0 * nq + 8.0 * m for m in voxels]))
         k_ms = ms[2] / max(launches.value, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(nq, "k_scale_features<7") if world == 1 else (None, None)
+        roofline = {
+            "bound": "hbm",
+            "kernel": "k_scale_features<7>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "measured_copy_GBps": copy_gbps,
+            "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "alg_bytes_per_launch": alg_bytes,
+            "kernel_ms_avg": k_ms,
+            "valu": valu_ceiling(nq, k_ms) if k_ms > 0 else None,
+            "note": "nominal bound is HBM (few bytes per unit of work); the binding ceiling is vector-ALU "
+                    "issue, see `valu`: instructions per wave, fp64 flop per query and the fraction of the "
+                    "fp64 vector peak they amount to at the measured query rate",
+        }
+        if classify:
+            metric, unit = "classified points/sec end-to-end (features + forest)", "points/s"
+            value = total_points * args.steps / elapsed
+        else:
+            metric, unit = "point-scale feature ops/sec", "point-scales/s"
+            value = total_points * n_scales * args.steps / elapsed
         record = {
-            "metric": "point-scale feature ops/sec",
+            "metric": metric,
             "value": value,
-            "unit": "point-scales/s",
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (strong or world == 1) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d points/GPU plane+pole+sphere scene, %d scales e=%s r=3e, "
+                "workload": "%s: %d-point plane+pole+sphere scene%s, %d scales e=%s r=3e, "
                             "query cloud = search cloud, rows in Morton order of the coarsest cell"
-                            % (args.workload, nq, n_scales, edges),
+                            % (args.workload, n_cloud, "" if (strong or world == 1) else " per GPU",
+                               n_scales, edges),
                 "points_per_gpu": nq,
                 "scales": n_scales,
                 "parallelism": "tiles%d" % world,
+                "scaling_mode": "single" if world == 1 else args.scaling,
+                "tiles": "one" if world == 1 else
+                         ("Morton-contiguous runs of one cloud" if strong else "one scene per rank, abutting"),
+                "halo": None if world == 1 else args.halo,
                 "search_points_incl_halo": int(n_local_search),
                 "halo_points_exchanged_per_step": int(total_halo),
                 "collectives": "none" if world == 1 else
-                               "all-gather(6 f64/rank) + all-to-all(counts) + all-to-all-v(halo rows) per step",
+                               ("nm_halo_exchange over RCCL: all-gather(6 f64) + all-gather(256 KB cell set) "
+                                "+ all-gather(counts) + grouped ncclSend/ncclRecv(halo rows) per step"
+                                if comm is not None else "torch.distributed over gloo (rehearsal)"),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_scale_features<7>",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "measured_copy_GBps": copy_gbps,
-                "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
-                "traffic": measured_traffic(nq) if world == 1 else None,
-                "traffic_source": "profiles/r1_final_traffic.json (rocprofv3 --pmc, separate passes)",
-                "alg_bytes_per_launch": alg_bytes,
-                "kernel_ms_avg": k_ms,
-                "note": "nominal bound is HBM, the measured one is vector-ALU issue: SQ_ACTIVE_INST_VALU "
-                        "covers 91 % of the kernel's duration on every SIMD (profiles/r1_final_traffic.json); "
-                        "PMC traffic is 1.09x the algorithmic bytes, nothing is re-read from HBM",
-            },
+            "roofline": roofline,
             "stage_ms_per_step": {
                 "cell_keys_and_sort": ms[0] / args.steps,
                 "index_build": ms[1] / args.steps,
@@ -291,22 +423,26 @@ def main():
             },
             "voxels_per_scale": voxels,
         }
-        if world == 1 and args.cpu_sample > 0:
-            record["cpu_baseline"] = cpu_baseline(points, edges, radii, args.cpu_sample)
-            workers = min(32, os.cpu_count() or 1)
-            if workers > 1:
-                try:
-                    record["cpu_baseline_multicore"] = cpu_baseline_multicore(
-                        points, edges, radii, args.cpu_sample, workers)
-                except Exception as err:   # noqa: BLE001 - a reported extra, never fatal
-                    record["cpu_baseline_multicore"] = {"error": str(err)[:200]}
-            try:
-                record["cpu_lattice_c"] = cpu_lattice_c(points, edges, radii, 2_000_000)
-            except Exception as err:       # noqa: BLE001
-                record["cpu_lattice_c"] = {"error": str(err)[:200]}
+        if classify:
+            f_ms = float(np.mean([a.elapsed_time(b) for a, b in forest_ms])) if forest_ms else None
+            n_classes = int(forest_arrays["value"].shape[1])
+            f_bytes = (8.0 * 4 * n_scales + 8.0 * 0 + 4.0) * nq      # features in, labels out
+            record["forest"] = {
+                "trees": int(len(forest_arrays["roots"])), "nodes": int(len(forest_arrays["left"])),
+                "classes": n_classes, "ms_per_step": f_ms,
+                "roofline": {"bound": "hbm", "kernel": "k_forest_eval_packed",
+                             "achieved": f_bytes / (f_ms * 1e-3) / 1e9 if f_ms else None,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": f_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if f_ms else None,
+                             "alg_bytes_per_launch": f_bytes, "traffic": None},
+            }
+        if cpu:
+            record.update(cpu)
         else:
             record["cpu_baseline"] = None
         print(json.dumps(record))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

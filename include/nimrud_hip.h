@@ -37,7 +37,8 @@ typedef enum nm_status {
                                 outside the device path's limits (see nm_lattice)                     */
     NM_ERR_WORKSPACE = -3,   /* d_work too small                                                       */
     NM_ERR_HIP = -4,         /* a HIP runtime call failed                                              */
-    NM_ERR_RADIUS = -5       /* radius / edge ratio outside the supported range                        */
+    NM_ERR_RADIUS = -5,      /* radius / edge ratio outside the supported range                        */
+    NM_ERR_COMM = -6         /* an RCCL call failed                                                    */
 } nm_status;
 
 /*
@@ -63,6 +64,19 @@ void        nm_destroy(nm_ctx* ctx);
 const char* nm_last_error(const nm_ctx* ctx);
 /* library ABI version (bumped on any signature change) */
 int         nm_abi_version(void);
+
+/* ---- asynchronous failures -------------------------------------------------------------------------
+ * every call is asynchronous, so a failure that only a kernel can detect (the occupancy-index builder
+ * running out of its bounded wait or of leaves; a lattice built on the device that cannot be addressed,
+ * geometry.py:59-60) cannot be the return value of the call that enqueued it.  such a failure is STICKY on
+ * the context: the library leaves a snapshot of its device-side status words behind every feature call,
+ * and the next nm_* call that launches work - or nm_check - returns NM_ERR_HIP / NM_ERR_LATTICE with a
+ * message once that snapshot has arrived, and keeps doing so until nm_clear_error.  results of the
+ * failed call must be discarded.  nm_check(ctx, 1) waits for the snapshot of the last call (call it after
+ * synchronising the stream, before trusting results); nm_check(ctx, 0) only looks.  no reference
+ * counterpart (the reference is synchronous and raises in place).                                     */
+int nm_check(nm_ctx* ctx, int wait);
+int nm_clear_error(nm_ctx* ctx);
 
 /* ---- in-library stage timing ----------------------------------------------------------------------
  * between nm_profile_begin and nm_profile_end every nm_scale_features call brackets its stages with
@@ -216,6 +230,62 @@ int nm_halo_pack(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, co
                  double* d_out, void* stream);
 int nm_copy_xyz(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, double* d_out,
                 void* stream);
+
+/* ---- multi-GPU tiling: cell-set halos -----------------------------------------------------------------
+ * a Morton-contiguous tile (what BASELINE's north_star shards by) is L-shaped: its bounding box, and with
+ * it a box halo, covers far more than the tile.  a tile's CELL SET is the set of cells of a coarse cubic
+ * grid occupied by its points, dilated by the margin: NM_HALO_CELLSET_WORDS 32-bit words, one bit per
+ * cell, cell index = (z * dim_y + y) * dim_x + x.  the grid is a pure function of the global extrema
+ * (d_global_minmax: 6 doubles on the device, identical on every rank) and the margin - cell edge margin/4
+ * unless that needs more than 2^21 cells - so every rank computes the same one without talking.
+ * nm_halo_cellset writes the caller's own set; nm_halo_count_cells / nm_halo_pack_cells are
+ * nm_halo_count / nm_halo_pack with "inside destination r's cell set" (d_cellsets: n_ranks sets back to
+ * back, e.g. straight out of an all-gather) in place of the box test.  same idea as the reference's
+ * query tile + grown search tile (prototypes/mso.py:892-927), for tiles of any shape.                */
+#define NM_HALO_CELLSET_WORDS 65536
+size_t nm_halo_cellset_workspace_bytes(void);
+int nm_halo_cellset(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                    const double* d_global_minmax, double margin, uint32_t* d_cellset,
+                    void* d_work, size_t work_bytes, void* stream);
+int nm_halo_count_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                        const double* d_global_minmax, double margin, const uint32_t* d_cellsets,
+                        int32_t n_ranks, int32_t skip, int64_t* d_counts, void* stream);
+int nm_halo_pack_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                       const double* d_global_minmax, double margin, const uint32_t* d_cellsets,
+                       int32_t n_ranks, int32_t skip, const int64_t* d_offsets, int64_t* d_cursor,
+                       double* d_out, void* stream);
+
+/* ---- multi-GPU tiling: the halo exchange over RCCL ------------------------------------------------------
+ * one process per GPU, one nm_ctx and one RCCL communicator per process.  the communicator is a plain
+ * ncclComm_t (passed as void*): create it with nm_comm_create from a 128-byte unique id that rank 0 got
+ * from nm_comm_unique_id and handed to the other ranks by any means (the Python host broadcasts it with
+ * torch.distributed, which is all it uses torch.distributed for), or pass one the host already owns.
+ *
+ * nm_halo_exchange is collective over the communicator.  every rank passes its tile (d_xyz: n rows) and
+ * the halo margin max_s(radius_s + sqrt(3)/2 edge_s); on return (the sends and receives are enqueued on
+ * `stream`) d_recv holds, in rank order, the rows of all other tiles that lie within the margin of this
+ * tile - by destination box (NM_HALO_BOXES) or by destination cell set (NM_HALO_CELLS, see above) -
+ * *h_recv_rows / *h_sent_rows (HOST) the row counts, and d_global_minmax (device, 6 doubles) the extrema of
+ * the WHOLE cloud, from which every rank builds the same lattices as a single-process run
+ * (geometry.py:37).  traffic: all-gather of 6 doubles, (cell mode) all-gather of 256 KB, all-gather of
+ * n_ranks + 2 int64, then grouped ncclSend / ncclRecv of 24-byte rows between the pairs that share a
+ * boundary.  the call synchronises `stream` ONCE, to learn the sizes.  when some rank's buffers are too
+ * small EVERY rank returns NM_ERR_WORKSPACE (with its own counts filled in) before anything is sent, so
+ * the hosts can grow their buffers and call again.  the send staging area is whatever d_work holds beyond
+ * nm_halo_workspace_bytes(0, n_ranks).  NM_HALO_INCLUDE_SELF (or-ed into mode) makes a rank its own
+ * neighbour as well - it then receives its own tile - which is how a one-rank communicator exercises the
+ * whole path.  no reference counterpart: the reference is single-process.                              */
+#define NM_COMM_ID_BYTES 128
+enum { NM_HALO_BOXES = 0, NM_HALO_CELLS = 1, NM_HALO_INCLUDE_SELF = 4 };
+int nm_comm_unique_id(void* id_out /* NM_COMM_ID_BYTES, host */);
+int nm_comm_create(nm_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id, void** comm_out);
+int nm_comm_destroy(nm_ctx* ctx, void* comm);
+size_t nm_halo_workspace_bytes(int64_t send_capacity_rows, int32_t n_ranks);
+int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t rank,
+                     const double* d_xyz, int64_t n, int64_t stride, double margin, int32_t mode,
+                     double* d_recv, int64_t recv_capacity_rows,
+                     int64_t* h_recv_rows, int64_t* h_sent_rows, double* d_global_minmax,
+                     void* d_work, size_t work_bytes, void* stream);
 
 /* ---- derived descriptors ------------------------------------------------
  * linearity (l1-l2)/l1, planarity (l2-l3)/l1 and scatter l3/l1 per scale, from the normalised

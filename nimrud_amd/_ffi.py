@@ -18,8 +18,10 @@ NM_ERR_LATTICE = -2
 NM_ERR_WORKSPACE = -3
 NM_ERR_HIP = -4
 NM_ERR_RADIUS = -5
+NM_ERR_COMM = -6
+NM_COMM_ID_BYTES = 128
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i64 = ctypes.c_int64
 c_i32 = ctypes.c_int32
@@ -51,6 +53,8 @@ SIGNATURES = {
     "nm_destroy": (None, [c_ptr]),
     "nm_last_error": (ctypes.c_char_p, [c_ptr]),
     "nm_abi_version": (ctypes.c_int, []),
+    "nm_check": (ctypes.c_int, [c_ptr, ctypes.c_int]),
+    "nm_clear_error": (ctypes.c_int, [c_ptr]),
     "nm_set_knn_fallback": (ctypes.c_int, [c_ptr, ctypes.c_int, c_f64]),
     "nm_profile_begin": (ctypes.c_int, [c_ptr]),
     "nm_set_overlap": (ctypes.c_int, [c_ptr, ctypes.c_int]),
@@ -86,6 +90,22 @@ SIGNATURES = {
     "nm_halo_pack": (ctypes.c_int,
                      [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nm_copy_xyz": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "nm_halo_cellset_workspace_bytes": (c_size, []),
+    "nm_halo_cellset": (ctypes.c_int,
+                        [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_f64, c_ptr, c_ptr, c_size, c_ptr]),
+    "nm_halo_count_cells": (ctypes.c_int,
+                            [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_f64, c_ptr, c_i32, c_i32, c_ptr,
+                             c_ptr]),
+    "nm_halo_pack_cells": (ctypes.c_int,
+                           [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_f64, c_ptr, c_i32, c_i32, c_ptr,
+                            c_ptr, c_ptr, c_ptr]),
+    "nm_comm_unique_id": (ctypes.c_int, [c_ptr]),
+    "nm_comm_create": (ctypes.c_int, [c_ptr, c_i32, c_i32, c_ptr, ctypes.POINTER(c_ptr)]),
+    "nm_comm_destroy": (ctypes.c_int, [c_ptr, c_ptr]),
+    "nm_halo_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "nm_halo_exchange": (ctypes.c_int,
+                         [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_i64, c_f64, c_i32, c_ptr, c_i64,
+                          ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, c_ptr, c_size, c_ptr]),
     "nm_descriptors": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i32, c_i64, c_ptr, c_i64, c_ptr]),
     "nm_forest_eval": (ctypes.c_int,
                        [c_ptr, ctypes.POINTER(NmForest), c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -5,7 +5,7 @@
 
 #include "nm_common.h"
 
-extern "C" int nm_abi_version(void) { return 3; }
+extern "C" int nm_abi_version(void) { return 4; }
 
 extern "C" int nm_create(nm_ctx** out, int device)
 {
@@ -13,19 +13,103 @@ extern "C" int nm_create(nm_ctx** out, int device)
     *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return NM_ERR_HIP;
-    if (hipSetDevice(device) != hipSuccess) return NM_ERR_HIP;
+    // the caller's current device is left as it was (torch reads the same process-wide setting)
+    nm_device_guard guard(device);
+    int now = -1;
+    if (hipGetDevice(&now) != hipSuccess || now != device) return NM_ERR_HIP;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return NM_ERR_HIP;
     nm_ctx* ctx = new nm_ctx();
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    // the sticky status words: the only memory the library owns (256 B on the device, 256 B pinned)
+    if (hipMalloc((void**)&ctx->d_status, NM_ST_WORDS * 4) != hipSuccess ||
+        hipMemset(ctx->d_status, 0, NM_ST_WORDS * 4) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->h_status, NM_ST_WORDS * 4, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->status_event, hipEventDisableTiming) != hipSuccess) {
+        nm_destroy(ctx);
+        return NM_ERR_HIP;
+    }
+    for (int i = 0; i < NM_ST_WORDS; ++i) ctx->h_status[i] = 0u;
     *out = ctx;
+    return NM_OK;
+}
+
+// ---- asynchronous failures ---------------------------------------------------------------------------
+// kernels report what the host cannot know when it enqueues them (an index build that timed out, a
+// lattice built on the device that cannot be addressed) by setting a word of ctx->d_status.  every
+// feature call ends with a snapshot of those words into pinned memory; whoever enters the library next
+// (or calls nm_check) sees a completed snapshot and gets the failure as a status code.  d_status is
+// never cleared by a kernel, so nothing is lost when snapshots overtake each other.
+void nm_status_snapshot(nm_ctx* ctx, hipStream_t s)
+{
+    if (!ctx->d_status) return;
+    if (hipMemcpyAsync(ctx->h_status, ctx->d_status, NM_ST_WORDS * 4, hipMemcpyDeviceToHost, s) !=
+        hipSuccess)
+        return;
+    if (hipEventRecord(ctx->status_event, s) == hipSuccess) ctx->status_pending = true;
+}
+
+int nm_status_poll(nm_ctx* ctx, bool wait)
+{
+    if (ctx->sticky) return ctx->sticky;
+    if (!ctx->status_pending) return NM_OK;
+    if (wait) {
+        if (hipEventSynchronize(ctx->status_event) != hipSuccess) return NM_OK;
+    } else if (hipEventQuery(ctx->status_event) != hipSuccess) {
+        return NM_OK;          // not there yet (or being captured): look again next time
+    }
+    ctx->status_pending = false;
+    const uint32_t* st = ctx->h_status;
+    if (st[NM_ST_LATTICE]) {
+        switch (st[NM_ST_LATTICE]) {
+            case NM_LAT_TOO_SMALL_EDGE: ctx->error = "edge length is too small to address this space"; break;
+            case NM_LAT_NO_EXTENT: ctx->error = "cloud has no extent beyond one voxel on some axis"; break;
+            case NM_LAT_DEVICE_LIMIT:
+                ctx->error = "an address width is outside the device path's range [1,30]";
+                break;
+            default: ctx->error = "cloud extrema are not finite"; break;
+        }
+        ctx->sticky = NM_ERR_LATTICE;
+    } else if (st[NM_ST_INDEX_TIMEOUT]) {
+        ctx->error = "occupancy index build timed out waiting for a leaf number: the features of an "
+                     "earlier call are incomplete";
+        ctx->sticky = NM_ERR_HIP;
+    } else if (st[NM_ST_LEAF_OVERFLOW]) {
+        ctx->error = "occupancy index ran out of leaves: the features of an earlier call are incomplete";
+        ctx->sticky = NM_ERR_HIP;
+    }
+    return ctx->sticky;
+}
+
+extern "C" int nm_check(nm_ctx* ctx, int wait)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    nm_device_guard guard(ctx->device);
+    return nm_status_poll(ctx, wait != 0);
+}
+
+extern "C" int nm_clear_error(nm_ctx* ctx)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    nm_device_guard guard(ctx->device);
+    // outstanding work may still set a word: drain the device first, then start clean
+    NM_HIP(ctx, hipDeviceSynchronize());
+    NM_HIP(ctx, hipMemset(ctx->d_status, 0, NM_ST_WORDS * 4));
+    for (int i = 0; i < NM_ST_WORDS; ++i) ctx->h_status[i] = 0u;
+    ctx->status_pending = false;
+    ctx->sticky = 0;
+    ctx->error.clear();
     return NM_OK;
 }
 
 extern "C" void nm_destroy(nm_ctx* ctx)
 {
     if (!ctx) return;
+    nm_device_guard guard(ctx->device);
+    if (ctx->status_event) (void)hipEventDestroy(ctx->status_event);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->sync_events) (void)hipEventDestroy(e);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
@@ -80,6 +164,7 @@ extern "C" int nm_profile_begin(nm_ctx* ctx)
 extern "C" int nm_profile_end(nm_ctx* ctx, double* ms, int64_t* launches)
 {
     if (!ctx) return NM_ERR_INVALID;
+    nm_device_guard guard(ctx->device);
     ctx->profiling = false;
     double acc[4] = {0, 0, 0, 0};
     int64_t calls = (int64_t)(ctx->events_used / 4);
@@ -231,7 +316,7 @@ __global__ __launch_bounds__(256) void k_forest_eval_packed(nm_forest F, const d
 extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, int64_t n,
                               int64_t feat_stride, double* d_proba, int32_t* d_label, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (!forest || n < 0 || (n > 0 && !d_feat) || (!d_proba && !d_label))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: bad arguments");
     if (!forest->d_packed && (!forest->d_left || !forest->d_right || !forest->d_feature ||
@@ -286,7 +371,7 @@ __global__ __launch_bounds__(256) void k_descriptors(const double* __restrict__ 
 extern "C" int nm_descriptors(nm_ctx* ctx, const double* d_feat, int64_t n, int32_t n_scales,
                               int64_t feat_stride, double* d_out, int64_t out_stride, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (n < 0 || n_scales < 0 || feat_stride < 4 * (int64_t)n_scales ||
         out_stride < 3 * (int64_t)n_scales || (n > 0 && n_scales > 0 && (!d_feat || !d_out)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_descriptors: bad arguments");

@@ -9,10 +9,31 @@
 
 #include "../../include/nimrud_hip.h"
 
+// sticky device-side status (nm_ctx::d_status, 64 words).  kernels only ever set words; the host reads a
+// snapshot that every feature call leaves behind (async copy to pinned memory + event) and turns a
+// non-zero word into NM_ERR_HIP / NM_ERR_LATTICE on the NEXT call or in nm_check - never a silent result.
+enum {
+    NM_ST_INDEX_TIMEOUT = 0,   // the index builder's bounded wait for a leaf number ran out
+    NM_ST_LEAF_OVERFLOW = 1,   // more occupied superblocks than the workspace has leaves for
+    NM_ST_LATTICE = 2,         // a lattice built on the device is not addressable (code below)
+    NM_ST_WORDS = 64
+};
+enum {
+    NM_LAT_TOO_SMALL_EDGE = 1,   // sum of widths > 64 (geometry.py:59-60)
+    NM_LAT_NO_EXTENT = 2,        // some width < 1 (the reference fails at geometry.py:74)
+    NM_LAT_DEVICE_LIMIT = 3,     // some width > 30: outside the device path's range
+    NM_LAT_NOT_FINITE = 4        // extrema are not finite numbers
+};
+
 struct nm_ctx {
     int device;
     std::string error;
     int num_cus;
+    uint32_t* d_status = nullptr;       // device, NM_ST_WORDS words, zero = healthy
+    uint32_t* h_status = nullptr;       // pinned host mirror of the last snapshot
+    hipEvent_t status_event = nullptr;  // completion of the last snapshot copy
+    bool status_pending = false;
+    int sticky = 0;                     // a past asynchronous failure: every later call returns it
     // stage timing (nm_profile_begin/end): events[4*k .. 4*k+3] bracket the three stages of call k
     bool profiling = false;
     std::vector<hipEvent_t> events;
@@ -42,6 +63,35 @@ static inline void nm_profile_mark(nm_ctx* ctx, hipStream_t s)
     }
     (void)hipEventRecord(ctx->events[ctx->events_used++], s);
 }
+
+// RAII: make the context's device current for the duration of an entry point and restore the caller's
+// (the process-wide current device is also what torch reads)
+struct nm_device_guard {
+    int prev = -1;
+    bool switched = false;
+    explicit nm_device_guard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~nm_device_guard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// defined in nm_api.hip: fold a completed status snapshot into ctx->sticky; returns the sticky status
+int nm_status_poll(nm_ctx* ctx, bool wait);
+// enqueue a snapshot of the device status words behind the work just enqueued on `s`
+void nm_status_snapshot(nm_ctx* ctx, hipStream_t s);
+
+// first lines of every entry point that launches work or creates streams / events
+#define NM_ENTER(ctx)                                   \
+    if (!(ctx)) return NM_ERR_INVALID;                  \
+    nm_device_guard _nm_guard((ctx)->device);           \
+    {                                                   \
+        const int _st = nm_status_poll((ctx), false);   \
+        if (_st) return _st;                            \
+    }
 
 #define NM_FAIL(ctx, code, ...)                                   \
     do {                                                          \
@@ -133,6 +183,7 @@ struct IndexDev {
     uint32_t* leaf;          // leaves, NM_LEAF_WORDS words each
     uint32_t leaf_capacity;  // leaves the workspace has room for
     uint32_t* counters;      // [0] leaves allocated, [1] occupied cells M (low), [2] overflow flag
+    uint32_t* status;        // the context's sticky status words (NM_ST_*)
 };
 
 #if defined(__HIPCC__)

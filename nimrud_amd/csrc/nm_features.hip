@@ -1344,7 +1344,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
                                  double* d_feat, int64_t feat_stride, int64_t* d_info, void* d_work,
                                  size_t work_bytes, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     int rc = check_scale_args(ctx, "nm_scale_features", d_query, n_query, query_stride, d_search,
                               n_search, search_stride, d_feat, feat_stride, d_work);
     if (rc) return rc;
@@ -1423,6 +1423,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
     nm_profile_mark(ctx, s);
     NM_HIP(ctx, hipGetLastError());
     if (d_info) k_publish_info<<<1, 64, 0, s>>>(I.counters, d_info);
+    nm_status_snapshot(ctx, s);
     return NM_OK;
 }
 
@@ -1498,7 +1499,7 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
                                       int64_t feat_stride, int64_t* d_info, void* d_work,
                                       size_t work_bytes, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (n_scales < 0 || (n_scales > 0 && (!lats || !radii)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: bad scale arguments");
     if (n_scales == 0) return NM_OK;
@@ -1559,7 +1560,7 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
     // every scale has its own index; all of them are cleared by one launch here and counted by one
     // launch at the end
     IndexDev index[NM_MAX_LADDER];
-    for (int i = 0; i < n_scales; ++i) index[i] = nm_index_at(w + S.index[i], S.ilay[i]);
+    for (int i = 0; i < n_scales; ++i) index[i] = nm_index_at(ctx, w + S.index[i], S.ilay[i]);
     rc = nm_index_clear_all(ctx, index, n_scales, s);
     if (rc) return rc;
 
@@ -1641,6 +1642,7 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         k_publish_info_all<<<1, 64, 0, s>>>(P, d_info);
         NM_HIP(ctx, hipGetLastError());
     }
+    nm_status_snapshot(ctx, s);
     return NM_OK;
 }
 
@@ -1711,7 +1713,7 @@ extern "C" int nm_scale_neighbors(nm_ctx* ctx, const double* d_query, int64_t n_
                                   const nm_lattice* lat, double radius, int32_t* d_nbr_count,
                                   const int64_t* d_nbr_offsets, int64_t* d_nbr_index, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (n_query < 0 || m < 0 || query_stride < 3 || (n_query > 0 && !d_query) || (m > 0 && !d_addr))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_neighbors: bad arguments");
     if (!d_nbr_count && !d_nbr_index)
@@ -1788,7 +1790,7 @@ extern "C" int nm_neighborhood_features(nm_ctx* ctx, const double* d_points, con
                                         const double* d_query, int64_t n_neighborhoods,
                                         double* d_feat, int64_t feat_stride, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (n_neighborhoods < 0 || feat_stride < 4 ||
         (n_neighborhoods > 0 && (!d_offsets || !d_query || !d_feat)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_neighborhood_features: bad arguments");

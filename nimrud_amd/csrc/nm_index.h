@@ -29,7 +29,7 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
 
 // ---- the ladder's indexes: one per scale, cleared and counted together --------------------------------
 constexpr int NM_MAX_LADDER = 32;     // scales per nm_multiscale_features call
-IndexDev nm_index_at(void* index_mem, const IndexLayout& lay);
+IndexDev nm_index_at(nm_ctx* ctx, void* index_mem, const IndexLayout& lay);
 int nm_index_clear_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s);
 int nm_index_count_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s);
 // index of lattice L from a spatially coherent coordinate stream (no sort), into a cleared index

@@ -87,7 +87,7 @@ __global__ void k_bounds_finish(uint64_t* mm)
 extern "C" int nm_bounds(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
                          double* d_minmax, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (!d_xyz || !d_minmax || n < 1 || stride < 3)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_bounds: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -137,7 +137,7 @@ extern "C" int nm_coordinate_to_address(nm_ctx* ctx, const double* d_xyz, int64_
                                         const nm_lattice* lat, int64_t* d_addr_out, int64_t* d_oob,
                                         void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (n < 0 || stride < 3 || (n > 0 && (!d_xyz || !d_addr_out)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_coordinate_to_address: bad arguments");
     int rc = validate_lattice(ctx, lat);
@@ -284,7 +284,7 @@ extern "C" int nm_voxelize(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t 
                            const nm_lattice* lat, int64_t* d_addr_out, int64_t* d_count,
                            void* d_work, size_t work_bytes, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (!d_xyz || !d_addr_out || !d_count || !d_work || n < 1 || stride < 3 ||
         n >= (int64_t)1 << 31)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_voxelize: bad arguments");
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_addr_to_coord(const int64_t* __restrict
 extern "C" int nm_address_to_coordinate(nm_ctx* ctx, const int64_t* d_addr, int64_t m,
                                         const nm_lattice* lat, double* d_xyz_out, void* stream)
 {
-    if (!ctx) return NM_ERR_INVALID;
+    NM_ENTER(ctx);
     if (m < 0 || (m > 0 && (!d_addr || !d_xyz_out)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_address_to_coordinate: bad arguments");
     int rc = validate_lattice(ctx, lat);
@@ -421,6 +421,7 @@ __global__ __launch_bounds__(256) void k_index_leaves(const uint64_t* __restrict
             const uint32_t idx = running + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (idx >= I.leaf_capacity) {
                 I.counters[2] = 1u;   // cannot happen when the workspace was sized by the library
+                I.status[NM_ST_LEAF_OVERFLOW] = 1u;
             } else {
                 uint4* leaf = (uint4*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
 #pragma unroll
@@ -535,6 +536,7 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
     I.counters = (uint32_t*)w;
     I.hash_mask = lay.hash_capacity - 1;
     I.leaf_capacity = lay.leaf_capacity;
+    I.status = ctx->d_status;
     NM_HIP(ctx, hipMemsetAsync(I.hash, 0xFF, (size_t)lay.hash_capacity * sizeof(HashEntry), s));
     NM_HIP(ctx, hipMemsetAsync(I.counters, 0, 256, s));
     int blocks = (int)((n + INDEX_CHUNK - 1) / INDEX_CHUNK);
@@ -601,6 +603,9 @@ constexpr uint32_t BITS_EMPTY = 0xFFFFFFFFu;     // free slot of a block's row-w
 // reader then waits for it.  that cannot deadlock: whoever entered a key is a running block, and a
 // block publishes its leaves before its own bit phase, i.e. before it ever waits for anybody.  the
 // wait is bounded all the same (counters[3] flags a timeout; the library then reports M = -1).
+#ifndef NM_SPIN_LIMIT
+#define NM_SPIN_LIMIT (1 << 22)
+#endif
 constexpr uint32_t LEAF_PENDING = 0xFFFFFFFFu;     // what the 0xFF-filled table holds before publication
 constexpr uint32_t LEAF_NONE = 0xFFFFFFFEu;        // published: no room (capacity overflow)
 
@@ -725,6 +730,7 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
                     __hip_atomic_store(leaf + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 I.counters[2] = 1u;
+                I.status[NM_ST_LEAF_OVERFLOW] = 1u;
             }
         }
         // the zeroes must have arrived before anyone can learn the leaf number
@@ -767,13 +773,18 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
         for (int g = 0; g < FUSED_GROUPS; ++g) {
             if (sb_head[g] && valid[g]) {
                 // not published yet: its creator is still in phase 1
-                for (int spin = 0; val[g] == LEAF_PENDING && spin < (1 << 22); ++spin) {
+                for (int spin = 0; val[g] == LEAF_PENDING && spin < NM_SPIN_LIMIT; ++spin) {
                     __builtin_amdgcn_s_sleep(8);
                     val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                 }
+#ifdef NM_DIAG_FORCE_TIMEOUT
+                // diagnostic build (tests only): the first block behaves as if its first wait ran out
+                if (blockIdx.x == 0 && it == 0 && g == 0) val[g] = LEAF_PENDING;
+#endif
                 if (val[g] == LEAF_PENDING) {
                     I.counters[3] = 1u;
+                    I.status[NM_ST_INDEX_TIMEOUT] = 1u;     // sticky: the next call into the library fails
                     val[g] = LEAF_NONE;
                 }
             }
@@ -940,7 +951,7 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
     return NM_OK;
 }
 
-IndexDev nm_index_at(void* index_mem, const IndexLayout& lay)
+IndexDev nm_index_at(nm_ctx* ctx, void* index_mem, const IndexLayout& lay)
 {
     char* w = (char*)index_mem;
     IndexDev I;
@@ -949,6 +960,7 @@ IndexDev nm_index_at(void* index_mem, const IndexLayout& lay)
     I.counters = (uint32_t*)w;
     I.hash_mask = lay.hash_capacity - 1;
     I.leaf_capacity = lay.leaf_capacity;
+    I.status = ctx->d_status;
     return I;
 }
 

@@ -33,6 +33,15 @@ class Runtime(object):
     def check(self, rc):
         _ffi.check(self.lib, self.ctx, rc)
 
+    def check_async(self, wait=True):
+        """raise what a kernel of an earlier call reported (nm_check): an occupancy index that timed out
+        or overflowed, a lattice built on the device that cannot be addressed.  wait=True waits for the
+        status snapshot of the last call - callers that have just synchronised pay nothing."""
+        self.check(self.lib.nm_check(self.ctx, 1 if wait else 0))
+
+    def clear_error(self):
+        self.check(self.lib.nm_clear_error(self.ctx))
+
     def stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -35,8 +35,15 @@ def neighborhood_features(points, offsets, query_points):
     off = torch.as_tensor(np.asarray(offsets) if not isinstance(offsets, torch.Tensor) else offsets,
                           dtype=torch.int64).to(rt.device).contiguous()
     nb = off.shape[0] - 1
+    if off.ndim != 1 or nb < 0:
+        raise ValueError("offsets must be a 1-D array of B+1 row numbers")
     if qry.shape[0] != nb:
         raise ValueError("one query point per neighborhood expected")
+    if nb > 0:
+        # the kernel trusts the offsets: they must be monotone row numbers inside `points`
+        lo, hi, steps = int(off[0]), int(off[-1]), off[1:] - off[:-1]
+        if lo < 0 or hi > pts.shape[0] or bool((steps < 0).any()):
+            raise ValueError("offsets must be non-decreasing and lie in [0, len(points)]")
     out = torch.empty((nb, 4), dtype=torch.float64, device=rt.device)
     rt.check(rt.lib.nm_neighborhood_features(rt.ctx, _device.ptr(pts), _device.ptr(off),
                                              _device.ptr(qry), nb, _device.ptr(out), 4,
@@ -58,7 +65,11 @@ def _single(query_point, neighborhood_points):
 
 def centroid(query_point, neighborhood_points):
     """distance between the query point and the mean of its neighborhood; 0 when the neighborhood is
-    empty (features.py:21-29)."""
+    empty (features.py:21-29).
+    one neighborhood per call means one upload, one launch and one download per call - milliseconds, like
+    `pca` below.  mapping these over neighborhoods the way the reference does (multiscale.py:109-116) is
+    only sensible for a handful; `neighborhood_features` is the batched form and
+    `multiscale.process_gpu` the real path."""
     return float(_single(query_point, neighborhood_points)[1])
 
 
@@ -72,7 +83,8 @@ def pca(neighborhood_points, strict=False):
     """the normalized variance of the first two principal components of the neighborhood
     (features.py:39-57): [largest, middle] eigenvalue of the ddof=1 covariance over the eigenvalue sum.
     fewer than two points -> zeros (the documented value, multiscale.py:4-5), or FloatingPointError
-    with strict=True (what numpy.cov makes the reference do)."""
+    with strict=True (what numpy.cov makes the reference do).
+    scalar convenience form (one launch per call): see the note on `centroid`."""
     if population(neighborhood_points) < 2:
         if strict:
             raise FloatingPointError("covariance undefined for fewer than 2 points")

@@ -82,11 +82,17 @@ def _ladder_lattices(lo, hi, edge_lengths):
     return lats
 
 
-def _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info, knn_min=0,
+def _ladder_into(rt, query, search, shared, bounds, edge_lengths, radii, out, info, knn_min=0,
                  knn_radius_factor=3.0):
     """enqueue the whole ladder in one library call (nm_multiscale_features): the cloud is sorted
-    once, every scale's index is built from that order."""
+    once, every scale's index is built from that order.  bounds: the search cloud's extrema, (lo, hi)
+    host arrays or a (6,) device tensor."""
     from nimrud_amd import _ffi
+    if isinstance(bounds, torch.Tensor):
+        mm = bounds.cpu().numpy()
+        lo, hi = mm[:3], mm[3:]
+    else:
+        lo, hi = bounds
     # the fallback switch is context state in the C ABI: always set it, so no call inherits another's
     rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
     n_scales = len(edge_lengths)
@@ -145,6 +151,14 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
     nq = query.shape[0]
     if out is None:
         out = torch.empty((nq, 4 * n_scales), dtype=torch.float64, device=rt.device)
+    elif not (isinstance(out, torch.Tensor) and out.dtype == torch.float64 and out.device == rt.device
+              and out.ndim == 2 and out.shape[0] == nq and out.shape[1] >= 4 * n_scales
+              and (out.shape[1] == 0 or out.stride(1) == 1)
+              and (nq <= 1 or out.stride(0) >= 4 * n_scales)):
+        # the kernels write 4*S doubles per row at the row pitch of `out`: anything else would put
+        # 8-byte stores outside the allocation
+        raise ValueError("out must be a (Nq, >= 4*S) fp64 tensor on the clouds' device with unit column "
+                         "stride")
     info = torch.zeros((max(n_scales, 1), 4), dtype=torch.int64, device=rt.device)
     if n_scales == 0:
         return (out, []) if return_info else out
@@ -176,7 +190,7 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
     try:
         if not (verbose or per_scale):
             covariance_columns(0)
-            _ladder_into(rt, query, search, shared, lo, hi, edge_lengths, radii, out, info,
+            _ladder_into(rt, query, search, shared, (lo, hi), edge_lengths, radii, out, info,
                          knn_min=knn_min, knn_radius_factor=knn_radius_factor)
             edge_lengths_loop = []
         else:
@@ -256,7 +270,11 @@ def process_single_core(query_cloud, search_cloud, edge_lengths, radii, verbose=
     query = search if shared else _device.as_cloud(query_cloud, rt.device)[1]
     result = process_gpu(query, search, edge_lengths, radii, verbose=verbose, strict=strict,
                          knn_min=knn_min, knn_radius_factor=knn_radius_factor)
-    return result.cpu().numpy()
+    host = result.cpu().numpy()
+    # the copy has synchronised the stream: anything a kernel of this call reported is in by now.  an
+    # incomplete result is never returned silently.
+    rt.check_async(wait=True)
+    return host
 
 
 def one_scale_single_core(query_cloud, search_cloud, edge_length, radius, verbose=False,

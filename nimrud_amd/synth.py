@@ -19,10 +19,15 @@ def uniform_cloud(n, extent=10.0, seed=0):
     return _round32(rs.rand(n, 3) * extent)
 
 
-def scene_cloud(n, extent=60.0, n_poles=200, n_spheres=40, seed=1, offset=(0.0, 0.0, 0.0)):
+def scene_cloud(n, extent=60.0, n_poles=200, n_spheres=40, seed=1, offset=(0.0, 0.0, 0.0),
+                five_class=False):
     """configs 2/3/5: 60 % ground plane on [0,extent]^2 (z ~ N(0, 0.01 m)), 10 % vertical poles
     (radius 0.05 m, height 6 m, xy jitter N(0, 0.01)), 30 % sphere shells (radius 1.5 m, radial noise
-    N(0, 0.01)).  points are shuffled so row order carries no spatial coherence."""
+    N(0, 0.01)).  points are shuffled so row order carries no spatial coherence.
+    labels: 0 ground, 1 pole, 2 sphere.  five_class=True (config 5) splits the ground by what stands on
+    it - 3 = ground within 0.6 m of a pole axis, 4 = ground under a sphere (within 1.5 m of a sphere
+    centre in plan), 0 = open ground - so the label still is the generating primitive plus its context,
+    and the five classes differ in their multiscale neighborhoods.  the points are the same either way."""
     rs = np.random.RandomState(seed)
     n_ground = int(round(0.6 * n))
     n_pole = int(round(0.1 * n))
@@ -50,8 +55,15 @@ def scene_cloud(n, extent=60.0, n_poles=200, n_spheres=40, seed=1, offset=(0.0, 
     sphere = centre[which] + direction * radius[:, None]
 
     points = np.concatenate((ground, pole, sphere), axis=0)
+    ground_label = np.zeros(n_ground, dtype=np.int32)
+    if five_class:
+        from scipy.spatial import cKDTree
+        d_sphere, _ = cKDTree(centre[:, :2]).query(ground[:, :2])
+        ground_label[d_sphere <= 1.5] = 4
+        d_pole, _ = cKDTree(pole_xy).query(ground[:, :2])
+        ground_label[d_pole <= 0.6] = 3
     labels = np.concatenate((
-        np.zeros(n_ground, dtype=np.int32),
+        ground_label,
         np.ones(n_pole, dtype=np.int32),
         np.full(n_sphere, 2, dtype=np.int32)))
     order = rs.permutation(n)
@@ -123,6 +135,12 @@ CONFIGS = {
                          radii=[0.15, 0.30, 0.60, 1.20, 2.40], morton=0.80),
     "c4_lidar_50m": dict(kind="lidar", n=50_000_000, seed=3, edges=[0.05, 0.10, 0.20, 0.40, 0.80],
                          radii=[0.15, 0.30, 0.60, 1.20, 2.40], knn_min=8),
+    # config 5 = the config 3 cloud (same seed, same points) with five-class labels, classified by the
+    # random forest of tests/golden/g6_forest_c5.npz (32 trees, depth <= 12) behind the last scale
+    "c5_scene_10m_rf": dict(kind="scene", n=10_000_000, extent=190.0, n_poles=2000, n_spheres=400,
+                            seed=2, edges=[0.05, 0.10, 0.20, 0.40, 0.80],
+                            radii=[0.15, 0.30, 0.60, 1.20, 2.40], morton=0.80, five_class=True,
+                            forest="g6_forest_c5.npz"),
 }
 
 
@@ -146,7 +164,7 @@ def make_config(name, n=None, seed_offset=0):
         points, labels = uniform_cloud(cfg["n"], cfg["extent"], cfg["seed"]), None
     else:
         points, labels = scene_cloud(cfg["n"], cfg["extent"], cfg["n_poles"], cfg["n_spheres"],
-                                     cfg["seed"])
+                                     cfg["seed"], five_class=bool(cfg.get("five_class")))
     if cfg.get("morton"):
         order = morton_sort(points, cfg["morton"])
         points = np.ascontiguousarray(points[order])

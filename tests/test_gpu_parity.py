@@ -347,6 +347,71 @@ def test_halo_kernels_against_numpy():
     assert np.array_equal(out.cpu().numpy(), pts)
 
 
+def test_cellset_kernels_against_numpy():
+    # the coarse cell sets of the Morton-tile halos: the device grid, the dilation and the bit packing
+    # against the numpy mirror the CPU tests use (tests/test_parallel_cpu.py), and count / pack by cell set
+    from nimrud_amd import parallel
+    from test_parallel_cpu import NumpyBackend
+    pts, _ = synth.scene_cloud(60000, extent=30.0, n_poles=20, n_spheres=6, seed=99)
+    parts = parallel.partition_by_morton(pts, 3, 0.4)
+    margin = parallel.halo_margin([0.1, 0.2, 0.4], [0.3, 0.6, 1.2])
+    glob = np.concatenate((pts.min(0), pts.max(0)))
+    dglob = torch.from_numpy(glob).cuda()
+    be, nb = parallel.HipBackend(), NumpyBackend()
+    sets = []
+    for part in parts:
+        tile = np.ascontiguousarray(pts[part])
+        got = be.cellset(torch.from_numpy(tile).cuda(), dglob, margin).cpu().numpy()
+        want = nb.cellset(torch.from_numpy(tile), torch.from_numpy(glob), margin).numpy()
+        assert np.array_equal(got, want)
+        assert 0 < np.unpackbits(got.view(np.uint8)).sum() < 32 * parallel.CELLSET_WORDS
+        sets.append(want)
+    dsets = torch.from_numpy(np.stack(sets)).cuda()
+    tile0 = np.ascontiguousarray(pts[parts[0]])
+    dest = (dglob, margin, dsets)
+    counts = be.halo_count(torch.from_numpy(tile0).cuda(), dest, 0).cpu().numpy()
+    hdest = (torch.from_numpy(glob), margin, torch.from_numpy(np.stack(sets)))
+    want_counts = nb.halo_count(torch.from_numpy(tile0), hdest, 0).numpy()
+    assert np.array_equal(counts, want_counts) and counts[0] == 0 and counts[1:].sum() > 0
+    offsets = np.concatenate(([0], np.cumsum(counts)[:-1]))
+    packed = be.halo_pack(torch.from_numpy(tile0).cuda(), dest, 0, torch.from_numpy(offsets).cuda(),
+                          int(counts.sum())).cpu().numpy()
+    want_rows = nb.halo_pack(torch.from_numpy(tile0), hdest, 0, torch.from_numpy(offsets),
+                             int(counts.sum())).numpy()
+    for j in range(1, 3):
+        a = packed[offsets[j]:offsets[j] + counts[j]]
+        b = want_rows[offsets[j]:offsets[j] + counts[j]]
+        assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+
+
+@pytest.mark.parametrize("halo", ["cells", "boxes"])
+def test_halo_exchange_through_rccl_one_rank(halo):
+    # nm_halo_exchange on real RCCL: a one-rank communicator created by the library itself, the rank its
+    # own neighbour (NM_HALO_INCLUDE_SELF), so the all-gathers, the pack, and a grouped ncclSend/ncclRecv
+    # of the whole tile run on hardware, on the stream the kernels use, into the buffer behind the tile.
+    # the search cloud then is [tile | tile]: same voxels, so the features must be bit-identical.
+    from nimrud_amd import parallel
+    pts, _ = synth.scene_cloud(50000, extent=16.0, n_poles=10, n_spheres=4, seed=103)
+    dev = torch.from_numpy(pts).cuda()
+    comm = parallel.RcclComm(rank=0, world=1)
+    try:
+        plan = parallel.TilePlan(dev, [0.1, 0.2, 0.4], [0.3, 0.6, 1.2], comm=comm, halo=halo)
+        plan.include_self = True
+        out = parallel.process_tile(plan)
+        torch.cuda.synchronize()
+        assert plan.halo_received == len(pts) and plan.halo_sent == len(pts)
+        halo_rows = plan._buffer[len(pts):2 * len(pts)].cpu().numpy()
+        assert np.array_equal(halo_rows[np.lexsort(halo_rows.T[::-1])], pts[np.lexsort(pts.T[::-1])])
+        want = multiscale.process_gpu(dev, dev, [0.1, 0.2, 0.4], [0.3, 0.6, 1.2])
+        assert torch.equal(out, want)
+        # a second step reuses the buffers; without the self-neighbour nothing is exchanged
+        plan.include_self = False
+        out2 = parallel.process_tile(plan)
+        assert plan.halo_received == 0 and torch.equal(out2, want)
+    finally:
+        comm.close()
+
+
 def test_prefix_query_mode_matches_separate_clouds():
     # queries = leading rows of the search buffer (what a tile + halo looks like)
     pts, _ = synth.scene_cloud(40000, extent=12.0, n_poles=8, n_spheres=3, seed=93)
@@ -356,8 +421,8 @@ def test_prefix_query_mode_matches_separate_clouds():
     be = parallel.HipBackend()
     out = torch.empty((n_query, 8), dtype=torch.float64, device="cuda")
     info = torch.zeros((2, 4), dtype=torch.int64, device="cuda")
-    lo, hi = pts.min(0), pts.max(0)
-    be.features(search, n_query, lo, hi, [0.1, 0.2], [0.3, 0.6], out, info)
+    bounds = torch.from_numpy(np.concatenate((pts.min(0), pts.max(0)))).cuda()
+    be.features(search, n_query, bounds, [0.1, 0.2], [0.3, 0.6], out, info)
     want = multiscale.process_gpu(search[:n_query].clone(), search, [0.1, 0.2], [0.3, 0.6])
     assert torch.equal(out, want)
     ref = oracle.process_fast(pts[:n_query], pts, [0.1, 0.2], [0.3, 0.6])
@@ -769,6 +834,163 @@ def test_config3_full_size_properties():
     for s, (e, r) in enumerate(zip(edges, radii)):
         want_s = oracle.one_scale_c(pts, pts, e, r)
         assert_features_close(f[:, 4 * s:4 * s + 4], want_s, pts)
+
+
+def test_index_timeout_is_sticky_and_never_silent(tmp_path):
+    # a diagnostic build of the library (make -C nimrud_amd/csrc diag) whose index builder behaves as if
+    # its bounded wait for a leaf number had run out in the first block.  the host API must refuse to hand
+    # back the incomplete features, and the context must keep failing until the error is cleared.
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(repo, "nimrud_amd", "diag", "libnimrud_hip_timeout.so")
+    assert os.path.exists(lib), "diagnostic build missing: make -C nimrud_amd/csrc diag"
+    script = tmp_path / "timeout_probe.py"
+    script.write_text("""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from nimrud_amd import synth, _ffi, device
+from nimrud_amd.minimal import multiscale
+pts = synth.uniform_cloud(20000, extent=4.0, seed=5)
+try:
+    multiscale.process_single_core(pts, pts, [0.1, 0.2], [0.3, 0.6])
+    print("RESULT silent")
+    raise SystemExit(0)
+except _ffi.NimrudHipError as err:
+    print("RESULT raised:", err)
+rt = device.get_runtime()
+dev = torch.from_numpy(pts).cuda()
+try:
+    multiscale.process_gpu(dev, dev, [0.1], [0.3])
+    print("RESULT second call went through")
+except _ffi.NimrudHipError:
+    print("RESULT sticky")
+rt.clear_error()
+out = multiscale.process_gpu(dev, dev, [0.1], [0.3])      # enqueued: the context is usable again
+torch.cuda.synchronize()
+try:
+    rt.check_async(wait=True)
+    print("RESULT no failure after clear")
+except _ffi.NimrudHipError:
+    print("RESULT failed again after clear")
+""" % repo)
+    env = dict(os.environ, NIMRUD_HIP_LIBRARY=lib)
+    run = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True,
+                         timeout=300)
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("RESULT")]
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert lines[0].startswith("RESULT raised:") and "timed out" in lines[0], run.stdout
+    assert lines[1] == "RESULT sticky", run.stdout
+    assert lines[2] == "RESULT failed again after clear", run.stdout     # the build fails every time
+
+
+def test_context_for_another_device_leaves_the_current_device_alone():
+    # nm_create used to hipSetDevice() and never restore it.  on a one-GPU box the only checkable part is
+    # that creating, using and destroying a context changes nothing the process can see.
+    import ctypes
+    from nimrud_amd import _ffi
+    lib = _ffi.load()
+    before = torch.cuda.current_device()
+    ctx = ctypes.c_void_p()
+    assert lib.nm_create(ctypes.byref(ctx), torch.cuda.device_count() - 1) == 0
+    assert torch.cuda.current_device() == before
+    assert lib.nm_check(ctx, 1) == 0
+    lib.nm_destroy(ctx)
+    assert torch.cuda.current_device() == before
+    assert lib.nm_create(ctypes.byref(ctx), torch.cuda.device_count()) != 0     # no such device
+
+
+def test_out_tensor_is_validated():
+    pts = synth.uniform_cloud(3000, extent=2.0, seed=171)
+    dev = torch.from_numpy(pts).cuda()
+    good = torch.empty((3000, 8), dtype=torch.float64, device="cuda")
+    assert multiscale.process_gpu(dev, dev, [0.2, 0.4], [0.6, 1.2], out=good) is good
+    for bad in (torch.empty((3000, 8), dtype=torch.float32, device="cuda"),
+                torch.empty((3000, 8), dtype=torch.float64),
+                torch.empty((2999, 8), dtype=torch.float64, device="cuda"),
+                torch.empty((3000, 7), dtype=torch.float64, device="cuda"),
+                torch.empty((8, 3000), dtype=torch.float64, device="cuda").t()):
+        with pytest.raises(ValueError):
+            multiscale.process_gpu(dev, dev, [0.2, 0.4], [0.6, 1.2], out=bad)
+    with pytest.raises(ValueError):
+        features.neighborhood_features(pts[:10], np.array([0, 4, 12]), pts[:2])
+    with pytest.raises(ValueError):
+        features.neighborhood_features(pts[:10], np.array([0, 6, 4]), pts[:2])
+
+
+def test_config5_forest_fixture(golden):
+    # the config 5 classifier on the fixture's own inputs: probabilities to 1e-15 of sklearn's, labels equal
+    g = golden("g6_forest_c5.npz")
+    model = classification.ForestModel.from_arrays(g)
+    proba = model.predict_proba(g["x"])
+    assert np.abs(proba - g["proba"]).max() <= 1e-15
+    assert np.array_equal(model.predict(g["x"]), g["label"])
+    # a feature matrix with extra columns and a row stride, as a slice of a wider tensor
+    wide = torch.zeros((len(g["x"]), 27), dtype=torch.float64, device="cuda")
+    wide[:, :20] = torch.from_numpy(g["x"]).cuda()
+    assert np.array_equal(model.predict(wide[:, :20]).cpu().numpy(), g["label"])
+
+
+def test_config5_full_size_end_to_end(golden):
+    # BASELINE config 5 as stated: 10 M points x 5 scales with the forest evaluated behind the last
+    # scale.  the fixture's evaluation rows tie the features of the full run to the oracle's (and through
+    # them sklearn's labels to ours); fused and stand-alone evaluation must agree on every row.
+    g = golden("g6_forest_c5.npz")
+    pts, labels, edges, radii = synth.make_config("c5_scene_10m_rf")
+    assert np.array_equal(np.asarray(edges), g["edges"]) and np.array_equal(np.asarray(radii), g["radii"])
+    model = classification.ForestModel.from_arrays(g)
+    dev = torch.from_numpy(pts).cuda()
+    label, feats = classification.classify_cloud(dev, edges, radii, model)
+    rows = g["eval_rows"]
+    f_eval = feats[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert_features_close(f_eval, g["x"], pts)
+    got = label.cpu().numpy()
+    assert np.array_equal(got[rows], g["truth"]) or (got[rows] == g["truth"]).mean() > 0.95
+    # same inputs -> same labels: the oracle's forest on the GPU's features of those rows
+    omodel = {k: g[k] for k in ("left", "right", "feature", "threshold", "value", "roots", "classes")}
+    assert np.array_equal(model.classes[got[rows]], oracle.forest_predict(omodel, f_eval))
+    # sklearn's labels on the oracle's features: a row can only differ where a feature rounds across a
+    # split threshold after the fp32 cast
+    assert (model.classes[got[rows]] != g["label"]).sum() <= 2
+    # stand-alone evaluation of the finished matrix: every one of the 1e7 labels identical
+    label2 = model.predict(feats)
+    assert torch.equal(torch.as_tensor(model.classes, device="cuda")[label.to(torch.int64)], label2)
+    proba = model.predict_proba(feats[:100000])
+    assert torch.equal(proba.argmax(1).to(torch.int32), label[:100000])
+    assert (got == labels).mean() > 0.95
+
+
+def test_fused_moments_against_golden_neighbor_lists(golden):
+    # the fused kernel's neighbor SET, pinned bit-exactly: population, centroid and covariance of the first
+    # 256 queries per scale recomputed in exact integer arithmetic from the REFERENCE's neighbor lists
+    # (tests/golden/g*_: s%d_nbr_index captured from cKDTree.query_ball_tree) must reproduce what the
+    # kernel derives from its own integer moments - the covariance output is n*S2 - S1*S1^T scaled, so a
+    # single wrong neighbor changes it far beyond the 1e-12 compared here.
+    for name in PIPELINE_FIXTURES:
+        g = golden(name)
+        pts = g["points"]
+        edges, radii = list(g["edges"]), list(g["radii"])
+        dev = torch.from_numpy(pts).cuda()
+        feats, cov = multiscale.process_gpu_covariance(dev, dev, edges, radii)
+        feats, cov = feats.cpu().numpy(), cov.cpu().numpy()
+        for s, e in enumerate(edges):
+            lat = oracle.Lattice(pts, e)
+            addr = g["s%d_addresses" % s]
+            cells = lat.address_to_cells(addr).astype(np.int64)       # (M, 3) integer lattice sites
+            off, idx = g["s%d_nbr_offsets" % s], g["s%d_nbr_index" % s]
+            for q in range(len(off) - 1):
+                nb = cells[idx[off[q]:off[q + 1]]]
+                n = len(nb)
+                assert feats[q, 4 * s] == n
+                if n < 2:
+                    continue
+                s1 = nb.sum(0)
+                s2 = nb.T @ nb
+                scatter = n * s2 - np.outer(s1, s1)                   # exact integers
+                want = scatter[np.triu_indices(3)] * (e * e) / (n * (n - 1.0))
+                got = cov[q, 6 * s:6 * s + 6]
+                assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (name, s, q)
 
 
 def test_config4_lidar_power_law_with_knn_fallback():

@@ -153,6 +153,24 @@ def test_oracle_operators_match_reference(golden):
             oracle.pca(nb, strict=True)
 
 
+def test_oracle_forest_config5_matches_sklearn(golden):
+    # the config 5 classifier (32 trees, depth <= 12, 5 classes; tests/golden/make_forest_c5.py)
+    g = golden("g6_forest_c5.npz")
+    assert len(g["roots"]) == 32 and g["value"].shape[1] == 5 and g["x"].shape == (4096, 20)
+    model = {k: g[k] for k in ("left", "right", "feature", "threshold", "value", "roots", "classes")}
+    proba = oracle.forest_predict_proba(model, g["x"])
+    assert np.abs(proba - g["proba"]).max() <= 1e-15
+    assert np.array_equal(oracle.forest_predict(model, g["x"]), g["label"])
+    # depth of the flattened trees
+    left, right = model["left"], model["right"]
+    depth = np.zeros(len(left), dtype=np.int64)
+    for node in range(len(left)):               # children come after their parent in sklearn's arrays
+        for child in (left[node], right[node]):
+            if child >= 0:
+                depth[child] = depth[node] + 1
+    assert depth.max() <= 12
+
+
 def test_oracle_forest_matches_reference(golden):
     g = golden("g5_forest.npz")
     model = {k: g[k] for k in ("left", "right", "feature", "threshold", "value", "roots", "classes")}
