@@ -101,6 +101,8 @@ def parse_args():
     ap.add_argument("--points", type=int, default=None, help="points of the cloud (default: the config's)")
     ap.add_argument("--overlap", type=int, default=None,
                     help="nm_set_overlap value (0 = sequential stages, 1 = pipelining)")
+    ap.add_argument("--fuse-scales", type=int, default=None,
+                    help="nm_set_fuse_scales value (1 = one search launch walks all scales, 0 = one per scale)")
     ap.add_argument("--cpu-sample", type=int, default=150000,
                     help="points of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
@@ -271,6 +273,8 @@ def main():
     rt = nm_device.get_runtime(dev)
     if args.overlap is not None:
         rt.check(rt.lib.nm_set_overlap(rt.ctx, args.overlap))
+    if args.fuse_scales is not None:
+        rt.check(rt.lib.nm_set_fuse_scales(rt.ctx, args.fuse_scales))
     model = classification.ForestModel.from_arrays(forest_arrays, device=dev) if classify else None
 
     if world > 1:
@@ -284,18 +288,16 @@ def main():
         def features_step():
             return multiscale.process_gpu(cloud, cloud, edges, radii, out=out)
 
-    forest_ms = []
+    fused = os.environ.get("NIMRUD_BENCH_FUSED_FOREST", "1") != "0"
 
     def step():
-        feats = features_step()
         if model is None:
-            return feats
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _, label, _ = model._eval(feats, False, True)
-        e1.record()
-        forest_ms.append((e0, e1))
-        return label
+            return features_step()
+        if world > 1:
+            feats = features_step()
+            return model._eval(feats, False, True)[1]
+        # config 5: the forest is evaluated inside the search kernel, behind each row's last scale
+        return classification.classify_cloud(cloud, edges, radii, model, fused=fused, out=out)[0]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -306,7 +308,6 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    forest_ms.clear()
     rt.lib.nm_profile_begin(rt.ctx)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -318,6 +319,18 @@ def main():
     launches = ctypes.c_int64(0)
     rt.check(rt.lib.nm_profile_end(rt.ctx, ctypes.byref(ms), ctypes.byref(launches)))
     rt.check_async(wait=True)
+    # config 5: the forest stage's share = the step with it minus the same step without (outside the timed
+    # region)
+    features_only_ms = None
+    if model is not None:
+        for _ in range(2):
+            features_step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            features_step()
+        fence()
+        features_only_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     # occupied voxels per scale (for the algorithmic byte count), outside the timed region
     _, info = multiscale.process_gpu(cloud, cloud, edges, radii, return_info=True) \
@@ -355,13 +368,17 @@ def main():
         nq = cloud.shape[0]
         # dominant kernel = k_scale_features<7>: per launch it reads the query coordinates (24 B) and
         # the occupied-voxel set (8 B per voxel as addresses) and writes 4 fp64 features (32 B).
-        alg_bytes = float(np.mean([56.0 * nq + 8.0 * m for m in voxels]))
+        # (with the scales of the ladder in one launch - the default - that launch does this once per scale:
+        # the bytes below are per launch, whatever the launch covers)
+        n_launch = max(launches.value, 1) / max(args.steps, 1)
+        alg_bytes = float(np.sum([56.0 * nq + 8.0 * m for m in voxels])) / n_launch
         k_ms = ms[2] / max(launches.value, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic(nq, "k_scale_features<7") if world == 1 else (None, None)
         roofline = {
             "bound": "hbm",
             "kernel": "k_scale_features<7>",
+            "scales_per_launch": n_scales / n_launch,
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -372,7 +389,7 @@ def main():
             "traffic_source": traffic_src,
             "alg_bytes_per_launch": alg_bytes,
             "kernel_ms_avg": k_ms,
-            "valu": valu_ceiling(nq, k_ms) if k_ms > 0 else None,
+            "valu": valu_ceiling(nq * n_scales / n_launch, k_ms) if k_ms > 0 else None,
             "note": "nominal bound is HBM (few bytes per unit of work); the binding ceiling is vector-ALU "
                     "issue, see `valu`: instructions per wave, fp64 flop per query and the fraction of the "
                     "fp64 vector peak they amount to at the measured query rate",
@@ -424,13 +441,17 @@ def main():
             "voxels_per_scale": voxels,
         }
         if classify:
-            f_ms = float(np.mean([a.elapsed_time(b) for a, b in forest_ms])) if forest_ms else None
+            f_ms = (elapsed / args.steps * 1e3 - features_only_ms) if features_only_ms else None
             n_classes = int(forest_arrays["value"].shape[1])
-            f_bytes = (8.0 * 4 * n_scales + 8.0 * 0 + 4.0) * nq      # features in, labels out
+            f_bytes = (8.0 * 4 * n_scales + 8.0 * 0 + 4.0) * nq      # features in, labels out (SURVEY 8d)
             record["forest"] = {
                 "trees": int(len(forest_arrays["roots"])), "nodes": int(len(forest_arrays["left"])),
-                "classes": n_classes, "ms_per_step": f_ms,
-                "roofline": {"bound": "hbm", "kernel": "k_forest_eval_packed",
+                "classes": n_classes, "fused_behind_last_scale": bool(fused and world == 1),
+                "features_only_ms_per_step": features_only_ms,
+                "ms_per_step": f_ms,
+                "roofline": {"bound": "hbm",
+                             "kernel": "forest epilogue of k_scale_features<7,true,forest>" if fused
+                                       else "k_forest_eval_packed8",
                              "achieved": f_bytes / (f_ms * 1e-3) / 1e9 if f_ms else None,
                              "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": f_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if f_ms else None,

@@ -82,15 +82,12 @@ int nm_clear_error(nm_ctx* ctx);
  * between nm_profile_begin and nm_profile_end every nm_scale_features call brackets its stages with
  * HIP events on the caller's stream.  nm_profile_end synchronises on them and returns the summed
  * device time in milliseconds: ms[0] cell keys + radix sort, ms[1] occupancy index build,
- * ms[2] the fused search/feature kernel, ms[3] reserved; *launches = fused-kernel launches timed.
+ * ms[2] the fused search/feature kernel(s), ms[3] reserved; *launches = search-kernel launches timed.
  * used by bench.py for the roofline figure; no reference counterpart (the reference's verbose mode
  * prints wall time per scale, multiscale.py:47-65).                                                */
 int nm_profile_begin(nm_ctx* ctx);
-/* nm_multiscale_features builds the occupancy indexes on an internal auxiliary stream while the fused
- * kernels run on the caller's stream (the caller's stream still orders the whole call).  OFF by
- * default: measured 2 % faster per step on MI355X (the VALU-bound kernel and the latency-bound builders
- * share the CUs, there is little to gain), but the in-library stage timing then only has a meaningful
- * ms[2], and that includes the slowdown of the kernels by the concurrent builders.                 */
+/* kept for ABI compatibility; no effect since ABI 5: one launch builds all indexes of a ladder before the
+ * first search kernel, there is nothing left to overlap (round 1 measured 2 % for the overlapped form).  */
 int nm_set_overlap(nm_ctx* ctx, int enabled);
 int nm_profile_end(nm_ctx* ctx, double* ms, int64_t* launches);
 
@@ -155,6 +152,29 @@ int nm_scale_features(nm_ctx* ctx,
  * stream without a sort.  d_info (nullable) receives 4 int64 per scale as in nm_scale_features.      */
 size_t nm_multiscale_workspace_bytes(int64_t n_query, int64_t n_search, const nm_lattice* lats,
                                      int32_t n_scales);
+/* consecutive scales with the same radius/edge ratio run in ONE launch of the search kernel (a wave keeps its
+ * 64 queries and walks the scales).  on by default; 0 = one launch per scale (same numbers).          */
+int nm_set_fuse_scales(nm_ctx* ctx, int enabled);
+
+/* ---- the whole scale ladder, lattices built on the device ----------------------------------------------
+ * process_single_core (multiscale.py:27-67) without a single value visiting the host: the search cloud's
+ * extrema (a bounds pass, or d_minmax: 6 doubles ON THE DEVICE {min xyz, max xyz}, e.g. the global extrema a
+ * multi-GPU job has agreed on) are turned into every scale's lattice by a kernel - VoxelFilter.__init__ /
+ * _calculate_shift, geometry.py:37-64, same arithmetic: min_corner = min - e/2, widths =
+ * ceil(log2((max_corner - min_corner)/e)) - and all later kernels read the lattices from device memory.
+ * nothing in the call waits for the device: it can be queued behind other work or captured in a hipGraph.
+ * what a host-side VoxelFilter would have raised (geometry.py:59-60 "edge length is too small to address
+ * this space"; no extent on an axis; a width outside the device path's [1,30]) is reported asynchronously
+ * as NM_ERR_LATTICE through nm_check (see there).  the workspace depends on the point counts only.
+ * bit-identical to nm_multiscale_features with the lattices the host would have built.                 */
+size_t nm_ladder_workspace_bytes(int64_t n_query, int64_t n_search, int32_t n_scales);
+int nm_ladder_features(nm_ctx* ctx,
+                       const double* d_query, int64_t n_query, int64_t query_stride,
+                       const double* d_search, int64_t n_search, int64_t search_stride,
+                       const double* edges, const double* radii, int32_t n_scales,
+                       const double* d_minmax,
+                       double* d_feat, int64_t feat_stride, int64_t* d_info,
+                       void* d_work, size_t work_bytes, void* stream);
 int nm_multiscale_features(nm_ctx* ctx,
                            const double* d_query, int64_t n_query, int64_t query_stride,
                            const double* d_search, int64_t n_search, int64_t search_stride,
@@ -341,10 +361,30 @@ typedef struct nm_forest {
     const int32_t* d_packed_roots;
     int32_t n_leaves;
     int32_t reserved;
+    /* optional compact layout of the same renumbered nodes (needs d_leaf_value and d_packed_roots too, and
+     * n_features <= 32): one 8-byte record per node {float threshold; uint32 packed}.  the threshold is the
+     * largest fp32 value not above the fp64 threshold - sklearn compares the fp32-cast feature with the fp64
+     * threshold, and x_f32 <= t_f64 holds exactly when x_f32 <= that value.  packed: bit 31 set = leaf, bits
+     * 30..0 its row in d_leaf_value; else bits 30..5 the left child's record, bits 4..0 the feature.
+     * preferred by nm_forest_eval when present; required by nm_set_forest_output.                       */
+    const void*    d_packed8;
 } nm_forest;
 
 int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, int64_t n,
                    int64_t feat_stride, double* d_proba, int32_t* d_label, void* stream);
+
+/* the classifier behind the last scale (BASELINE config 5: "random-forest classifier evaluation fused after
+ * feature assembly").  while a forest is set, nm_multiscale_features / nm_ladder_features evaluate it on
+ * every query row right after the row's last scale, inside the search kernel: the wave that has just written
+ * the row reads its 4*S features back while they are still in the XCD's L2, and its 64 lanes - neighbours in
+ * space - walk nearly the same paths.  d_proba (n_query, proba_stride) and d_label int32[n_query], rows in
+ * query order, either may be NULL; same numbers as nm_forest_eval on the finished matrix (which is what
+ * runs instead when the last scale has an unusual radius/edge ratio or the kNN fallback is on).  limits:
+ * n_features == 4 * n_scales <= 20, n_classes <= 8, the d_packed8 layout.  context state, like the
+ * covariance output; pass forest = NULL to switch it off.  the struct is copied, the arrays must stay
+ * alive.                                                                                               */
+int nm_set_forest_output(nm_ctx* ctx, const nm_forest* forest, double* d_proba, int64_t proba_stride,
+                         int32_t* d_label);
 
 #ifdef __cplusplus
 }

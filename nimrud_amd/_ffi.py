@@ -21,7 +21,7 @@ NM_ERR_RADIUS = -5
 NM_ERR_COMM = -6
 NM_COMM_ID_BYTES = 128
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_i64 = ctypes.c_int64
 c_i32 = ctypes.c_int32
@@ -42,7 +42,7 @@ class NmForest(ctypes.Structure):
                 ("d_value", c_ptr), ("d_roots", c_ptr), ("n_nodes", c_i32), ("n_trees", c_i32),
                 ("n_classes", c_i32), ("n_features", c_i32), ("d_packed", c_ptr),
                 ("d_leaf_value", c_ptr), ("d_packed_roots", c_ptr), ("n_leaves", c_i32),
-                ("reserved", c_i32)]
+                ("reserved", c_i32), ("d_packed8", c_ptr)]
 
 
 _LATP = ctypes.POINTER(NmLattice)
@@ -77,6 +77,13 @@ SIGNATURES = {
                                [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, _LATP,
                                 ctypes.POINTER(c_f64), c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_size,
                                 c_ptr]),
+    "nm_set_fuse_scales": (ctypes.c_int, [c_ptr, ctypes.c_int]),
+    "nm_ladder_workspace_bytes": (c_size, [c_i64, c_i64, c_i32]),
+    "nm_ladder_features": (ctypes.c_int,
+                           [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, ctypes.POINTER(c_f64),
+                            ctypes.POINTER(c_f64), c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_size,
+                            c_ptr]),
+    "nm_set_forest_output": (ctypes.c_int, [c_ptr, ctypes.POINTER(NmForest), c_ptr, c_i64, c_ptr]),
     "nm_field_workspace_bytes": (c_size, [c_i64, c_i64, _LATP, c_i32]),
     "nm_field_mean": (ctypes.c_int,
                       [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i32, _LATP, c_f64,

@@ -5,7 +5,7 @@
 
 #include "nm_common.h"
 
-extern "C" int nm_abi_version(void) { return 4; }
+extern "C" int nm_abi_version(void) { return 5; }
 
 extern "C" int nm_create(nm_ctx** out, int device)
 {
@@ -153,11 +153,54 @@ extern "C" int nm_set_normal_output(nm_ctx* ctx, double* d_normal, int64_t norma
     return NM_OK;
 }
 
+extern "C" int nm_set_fuse_scales(nm_ctx* ctx, int enabled)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    ctx->fuse_scales = enabled != 0;
+    return NM_OK;
+}
+
+extern "C" int nm_set_forest_output(nm_ctx* ctx, const nm_forest* forest, double* d_proba,
+                                    int64_t proba_stride, int32_t* d_label)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (!forest) {
+        ctx->forest_on = false;
+        return NM_OK;
+    }
+    if (!forest->d_packed8 || !forest->d_leaf_value || !forest->d_packed_roots)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_forest_output: the forest needs the 8-byte node layout "
+                                     "(d_packed8, d_leaf_value, d_packed_roots)");
+    if (forest->n_features < 1 || forest->n_features > NM_FUSED_FOREST_FEATURES ||
+        (forest->n_features & 3) || forest->n_classes < 1 ||
+        forest->n_classes > NM_FUSED_FOREST_CLASSES || forest->n_trees < 1)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_forest_output: behind the ladder a forest may have up to %d "
+                                     "features (4 per scale) and %d classes; evaluate larger ones with "
+                                     "nm_forest_eval", NM_FUSED_FOREST_FEATURES, NM_FUSED_FOREST_CLASSES);
+    if ((!d_proba && !d_label) || (d_proba && proba_stride < forest->n_classes))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_forest_output: bad output arguments");
+    ForestDev F;
+    F.nodes = (const uint2*)forest->d_packed8;
+    F.leaf_value = forest->d_leaf_value;
+    F.roots = forest->d_packed_roots;
+    F.n_trees = forest->n_trees;
+    F.n_classes = forest->n_classes;
+    F.n_features = forest->n_features;
+    F.proba = d_proba;
+    F.pstride = proba_stride;
+    F.label = d_label;
+    ctx->forest = F;
+    ctx->forest_features = forest->n_features;
+    ctx->forest_on = true;
+    return NM_OK;
+}
+
 extern "C" int nm_profile_begin(nm_ctx* ctx)
 {
     if (!ctx) return NM_ERR_INVALID;
     ctx->profiling = true;
     ctx->events_used = 0;
+    ctx->profile_launches = 0;
     return NM_OK;
 }
 
@@ -177,7 +220,7 @@ extern "C" int nm_profile_end(nm_ctx* ctx, double* ms, int64_t* launches)
         }
     }
     if (ms) for (int i = 0; i < 4; ++i) ms[i] = acc[i];
-    if (launches) *launches = calls;
+    if (launches) *launches = ctx->profile_launches;
     ctx->events_used = 0;
     return NM_OK;
 }
@@ -313,6 +356,82 @@ __global__ __launch_bounds__(256) void k_forest_eval_packed(nm_forest F, const d
     if (label) label[i] = best;
 }
 
+// the same evaluator on 8-byte nodes {fp32 threshold rounded down, packed} (nm_forest::d_packed8): half the
+// bytes per node visit.  x_f32 <= threshold_f64  <=>  x_f32 <= largest fp32 not above the threshold.
+constexpr int NM_FOREST8_MAX_FEATURES = 32;     // 5-bit feature field
+
+__global__ __launch_bounds__(256) void k_forest_eval_packed8(ForestDev F, const double* __restrict__ feat,
+                                                             int64_t n, int64_t fstride)
+{
+    __shared__ float xs[NM_FOREST8_MAX_FEATURES * 256];
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int nf = F.n_features;
+    const int rows_here = (int)((n - row0) < 256 ? (n - row0) : 256);
+    for (int r = threadIdx.x / 32; r < rows_here; r += 8) {
+        const double* src = feat + (row0 + r) * fstride;
+        for (int f = threadIdx.x % 32; f < nf; f += 32) xs[f * 256 + r] = (float)src[f];
+    }
+    __syncthreads();
+    const int64_t i = row0 + threadIdx.x;
+    if (i >= n) return;
+    double acc[NM_MAX_CLASSES];
+#pragma unroll
+    for (int c = 0; c < NM_MAX_CLASSES; ++c) acc[c] = 0.0;
+    for (int t0 = 0; t0 < F.n_trees; t0 += NM_FOREST_TREES) {
+        uint2 rec[NM_FOREST_TREES];
+#pragma unroll
+        for (int g = 0; g < NM_FOREST_TREES; ++g) {
+            const int t = t0 + g < F.n_trees ? t0 + g : F.n_trees - 1;
+            rec[g] = F.nodes[F.roots[t]];
+        }
+        bool any = true;
+        while (any) {
+            any = false;
+#pragma unroll
+            for (int g = 0; g < NM_FOREST_TREES; ++g) {
+                if (!(rec[g].y >> 31)) {
+                    const float v = xs[(rec[g].y & 31u) * 256 + threadIdx.x];
+                    rec[g] = F.nodes[(rec[g].y >> 5) + (v <= __uint_as_float(rec[g].x) ? 0u : 1u)];
+                    any = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NM_FOREST_TREES; ++g) {
+            if (t0 + g >= F.n_trees) break;
+            const double* val = F.leaf_value + (int64_t)(rec[g].y & 0x7FFFFFFFu) * F.n_classes;
+#pragma unroll
+            for (int c = 0; c < NM_MAX_CLASSES; ++c)
+                if (c < F.n_classes) acc[c] += val[c];
+        }
+    }
+    int best = 0;
+    double bestv = -1.0;
+#pragma unroll
+    for (int c = 0; c < NM_MAX_CLASSES; ++c) {
+        if (c < F.n_classes) {
+            const double pr = acc[c] / (double)F.n_trees;
+            if (F.proba) F.proba[i * F.pstride + c] = pr;
+            if (pr > bestv) {
+                bestv = pr;
+                best = c;
+            }
+        }
+    }
+    if (F.label) F.label[i] = best;
+}
+
+int nm_forest_rows(nm_ctx* ctx, const ForestDev& F, const double* d_feat, int64_t feat_stride, int64_t n,
+                   int32_t n_features, hipStream_t s)
+{
+    if (n <= 0) return NM_OK;
+    ForestDev G = F;
+    G.n_features = n_features;
+    k_forest_eval_packed8<<<(int)((n + 255) / 256), 256, 0, s>>>(G, d_feat, n, feat_stride);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
 extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, int64_t n,
                               int64_t feat_stride, double* d_proba, int32_t* d_label, void* stream)
 {
@@ -329,6 +448,21 @@ extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double
     if (n == 0) return NM_OK;
     const bool packed = forest->d_packed && forest->d_leaf_value && forest->d_packed_roots &&
                         forest->n_features <= NM_FOREST_MAX_FEATURES;
+    const bool packed8 = forest->d_packed8 && forest->d_leaf_value && forest->d_packed_roots &&
+                         forest->n_features <= NM_FOREST8_MAX_FEATURES;
+    if (packed8) {
+        ForestDev F;
+        F.nodes = (const uint2*)forest->d_packed8;
+        F.leaf_value = forest->d_leaf_value;
+        F.roots = forest->d_packed_roots;
+        F.n_trees = forest->n_trees;
+        F.n_classes = forest->n_classes;
+        F.n_features = forest->n_features;
+        F.proba = d_proba;
+        F.pstride = forest->n_classes;
+        F.label = d_label;
+        return nm_forest_rows(ctx, F, d_feat, feat_stride, n, forest->n_features, (hipStream_t)stream);
+    }
     if (packed)
         k_forest_eval_packed<<<(int)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
             *forest, d_feat, n, feat_stride, d_proba, d_label);

@@ -25,6 +25,20 @@ enum {
     NM_LAT_NOT_FINITE = 4        // extrema are not finite numbers
 };
 
+constexpr int NM_FUSED_FOREST_FEATURES = 21;    // 21 * 64 * 4 B = the LDS the search phase leaves behind
+constexpr int NM_FUSED_FOREST_CLASSES = 8;
+
+// the classifier behind the last scale (nm_set_forest_output): 8-byte nodes, see nm_forest::d_packed8
+struct ForestDev {
+    const uint2* nodes;          // {fp32 threshold rounded down, packed}: bit 31 leaf; else left << 5 | feature
+    const double* leaf_value;    // (n_leaves, n_classes), rows sum to 1
+    const int32_t* roots;        // root node of each tree
+    int32_t n_trees, n_classes, n_features;
+    double* proba;               // (Nq, pstride) or null
+    int64_t pstride;
+    int32_t* label;              // (Nq,) or null
+};
+
 struct nm_ctx {
     int device;
     std::string error;
@@ -50,7 +64,18 @@ struct nm_ctx {
     int64_t normal_stride = 0;
     int knn_k = 0;
     double knn_radius_factor = 3.0;
+    // classifier behind the last scale of the ladder (nm_set_forest_output)
+    bool forest_on = false;
+    ForestDev forest{};
+    int forest_features = 0;
+    // consecutive scales with the same candidate window run in one launch (nm_set_fuse_scales)
+    bool fuse_scales = true;
+    int64_t profile_launches = 0;   // search-kernel launches since nm_profile_begin
 };
+
+// classifier on the rows of a finished feature matrix, into F.proba / F.label (nm_api.hip)
+int nm_forest_rows(nm_ctx* ctx, const ForestDev& F, const double* d_feat, int64_t feat_stride, int64_t n,
+                   int32_t n_features, hipStream_t s);
 
 // next profiling event recorded on `s`, or a no-op when profiling is off
 static inline void nm_profile_mark(nm_ctx* ctx, hipStream_t s)
@@ -185,6 +210,34 @@ struct IndexDev {
     uint32_t* counters;      // [0] leaves allocated, [1] occupied cells M (low), [2] overflow flag
     uint32_t* status;        // the context's sticky status words (NM_ST_*)
 };
+
+// ---- the scale ladder in device memory ------------------------------------------------------------------
+// everything a kernel needs to know about one analysis scale.  the ladder path keeps an array of these in
+// its workspace: written by k_put_ladder from host lattices (nm_multiscale_features) or built on the device
+// from the cloud's extrema (nm_ladder_features), so that no lattice ever has to visit the host.
+struct ScaleDev {
+    LatticeDev L;
+    IndexDev I;
+    double r2;               // radius * radius (fp64 product, as scipy forms it)
+    int32_t valid;           // 0: the lattice cannot be addressed; every kernel leaves at once
+    int32_t prune_ok;        // static pruning of the candidate window is sound for this lattice
+};
+
+// how the three axes share the compact Z-order key of the one-time spatial sort (k_order_keys)
+struct ZLayout {
+    int32_t w1, w2;          // smallest and middle width
+    int32_t off2[3];         // slot of an axis in the 2-way zone, -1 for the axis with the smallest width
+};
+
+struct OrderDev {
+    LatticeDev L;            // the finest lattice of the ladder
+    ZLayout Z;
+    int32_t morton;          // 1: compact Z-order key, 0: superblock key (some width above 21 bits)
+    int32_t shift;           // low key bits dropped so that the key fits 32 bits
+    int32_t valid;
+};
+
+constexpr int NM_MAX_LADDER = 32;     // scales per ladder call
 
 #if defined(__HIPCC__)
 

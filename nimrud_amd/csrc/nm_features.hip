@@ -31,6 +31,9 @@ constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anch
 #endif
 constexpr int NM_BOX_EX = 62;   // x extent of a staged box: 64-bit rows, kept shifted left by two
 
+// one launch of the search kernel: the scales [s_begin, s_end) of a ladder whose per-scale data (lattice,
+// index, r^2) lives in device memory.  all scales of one launch share the candidate window (W, dmin) and
+// the static row bounds.
 struct ScaleArgs {
     const double* query;
     int64_t nq;              // rows of the query cloud
@@ -38,23 +41,25 @@ struct ScaleArgs {
     int64_t qstride;
     const uint32_t* order;   // order[slot] = query row processed in sorted slot `slot`
     int32_t direct;          // 1: `query` is already in slot order, (n_slots,3); rows go to order[slot]
-    LatticeDev L;
-    IndexDev I;
-    double r2;               // radius * radius (fp64 product, as scipy forms it)
+    const ScaleDev* scales;  // device array, one entry per scale of the ladder
+    int32_t s_begin, s_end;
     int32_t dmin;            // first candidate offset (= -(W-1)/2)
     int32_t W;               // candidates per axis
-    double* feat;
+    double* feat;            // scale s writes columns 4s..4s+3 of every row
     int64_t fstride;
-    uint32_t* stats;         // [0] neighborhoods with population < 2, [1] extra passes
-    // kNN fallback on: one bit per slot, set where the population came out below sparse_k (else null)
+    // kNN fallback on: one bit per slot and scale (scale s at sparse + s * sparse_words), set where the
+    // population came out below sparse_k (else null)
     unsigned long long* sparse;
+    int64_t sparse_words;
     int32_t sparse_k;
-    // covariance output on: upper triangle per row (already offset to this scale's six columns), else null
+    // covariance output on: upper triangle per row, scale s at columns 6s..6s+5, else null
     double* cov;
     int64_t cstride;
-    // normal output on: three columns per row (already offset to this scale), else null
+    // normal output on: scale s at columns 3s..3s+2, else null
     double* normal;
     int64_t nstride;
+    // classifier behind the last scale (FOREST kernels): rows of n_features = 4 * scales of the ladder
+    ForestDev F;
 };
 
 // ---- 3x3 symmetric eigenvalues, fp64, non-iterative ------------------------------------------------
@@ -548,25 +553,183 @@ constexpr MomentLut<W> nm_make_lut()
 template <int W>
 __device__ const MomentLut<W> NM_LUT = nm_make_lut<W>();
 
-template <int W, bool RHO3>
-__global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTable RT)
+// ---- per-lane slow path: any W, direct index lookups (no staging) -------------------------------------------
+// used by the generic kernel (unusual radius/edge ratios) and, inside the table kernels, for lattices whose
+// coordinates are so large that the static pruning of the window is not sound.  same arithmetic.
+__device__ __forceinline__ void nm_lane_generic(const ScaleArgs& A, const LatticeDev& L, const IndexDev& I,
+                                                double r2, int32_t s, uint32_t qi, double qx, double qy,
+                                                double qz, bool* sparse_out)
+{
+    const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
+    const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
+    const int32_t hz = nm_clamp_cell(nm_cell_f(qz, L.min_z, L.edge));
+    const int32_t W = A.W, dmin = A.dmin;
+    double n = 0, sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    for (int32_t k = 0; k < W; ++k) {
+        const int32_t gz = hz + dmin + k;
+        if (gz < 0 || gz >= (1 << L.wz)) continue;
+        double d = qz - nm_centre(gz, L.min_z, L.edge, L.half_edge);
+        const double dz2 = d * d;
+        for (int32_t j = 0; j < W; ++j) {
+            const int32_t gy = hy + dmin + j;
+            if (gy < 0 || gy >= (1 << L.wy)) continue;
+            d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
+            const double dy2 = d * d;
+            int32_t cached_sb = INT32_MIN;
+            uint32_t word = 0;
+            for (int32_t i = 0; i < W; ++i) {
+                const int32_t gx = hx + dmin + i;
+                if (gx < 0 || gx >= (1 << L.wx)) continue;
+                const int32_t sbx = gx >> NM_SBX_BITS;
+                if (sbx != cached_sb) {
+                    cached_sb = sbx;
+                    int32_t leaf = nm_hash_find(
+                        I, nm_sb_key((uint32_t)sbx, (uint32_t)(gy >> NM_SBY_BITS),
+                                     (uint32_t)(gz >> NM_SBZ_BITS), L));
+                    word = leaf >= 0 ? I.leaf[(size_t)leaf * NM_LEAF_WORDS + (gz & 7) * 8 + (gy & 7)]
+                                     : 0u;
+                }
+                if (!((word >> (gx & 31)) & 1u)) continue;
+                d = qx - nm_centre(gx, L.min_x, L.edge, L.half_edge);
+                const double sq = (d * d + dy2) + dz2;
+                if (sq <= r2) {
+                    n += 1.0;
+                    sx += i;
+                    sy += j;
+                    sz += k;
+                    sxx += (double)i * i;
+                    sxy += (double)i * j;
+                    sxz += (double)i * k;
+                    syy += (double)j * j;
+                    syz += (double)j * k;
+                    szz += (double)k * k;
+                }
+            }
+        }
+    }
+    double out[4];
+    const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
+    const double uy = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
+    const double uz = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
+    nm_features_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, ux, uy, uz, (double)dmin,
+                             L.edge, out);
+    double* o = A.feat + (int64_t)qi * A.fstride + 4 * s;
+    o[0] = out[0];
+    o[1] = out[1];
+    o[2] = out[2];
+    o[3] = out[3];
+    if (A.cov)
+        nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
+                                   A.cov + (int64_t)qi * A.cstride + 6 * s);
+    if (A.normal)
+        nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0,
+                               A.normal + (int64_t)qi * A.nstride + 3 * s);
+    if (n < 2.0) atomicAdd(&I.counters[8], 1u);
+    *sparse_out = n < (double)A.sparse_k;
+}
+
+// ---- the classifier behind the last scale ---------------------------------------------------------------------
+// sklearn's RandomForestClassifier.predict / predict_proba (prototypes/apc.py:1463,1022,1034) on the row the
+// wave has just finished: the lane's 4S features are read back from the feature matrix - the lines this very
+// wave wrote moments ago, served by the XCD's L2 when the scales run in one launch - cast to fp32 as sklearn
+// does and staged in LDS ([feature][lane], conflict-free), then every lane walks the trees, eight at a
+// time.  the 64 lanes of a wave are neighbours in space: their paths mostly coincide, so a node fetch
+// touches few cache lines.  node = 8 bytes {fp32 threshold, packed}; x_f32 <= threshold_f64 is evaluated as
+// x_f32 <= largest fp32 not above the threshold, which is the same predicate.
+constexpr int NM_FUSED_FOREST_TREES = 8;        // descents in flight per lane
+
+__device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, float* xs, int lane, bool have,
+                                                   uint32_t qi)
+{
+    const ForestDev& F = A.F;
+    if (have) {
+        const double* row = A.feat + (int64_t)qi * A.fstride;
+        for (int f = 0; f < F.n_features; ++f) xs[f * 64 + lane] = (float)row[f];
+    }
+    lds_fence();
+    if (!have) return;
+    double acc[NM_FUSED_FOREST_CLASSES];
+#pragma unroll
+    for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c) acc[c] = 0.0;
+    for (int t0 = 0; t0 < F.n_trees; t0 += NM_FUSED_FOREST_TREES) {
+        uint2 rec[NM_FUSED_FOREST_TREES];
+#pragma unroll
+        for (int g = 0; g < NM_FUSED_FOREST_TREES; ++g) {
+            const int t = t0 + g < F.n_trees ? t0 + g : F.n_trees - 1;
+            rec[g] = F.nodes[F.roots[t]];
+        }
+        bool any = true;
+        while (any) {
+            any = false;
+#pragma unroll
+            for (int g = 0; g < NM_FUSED_FOREST_TREES; ++g) {
+                if (!(rec[g].y >> 31)) {
+                    const float v = xs[(rec[g].y & 31u) * 64 + lane];
+                    const uint32_t left = rec[g].y >> 5;
+                    rec[g] = F.nodes[left + (v <= __uint_as_float(rec[g].x) ? 0u : 1u)];
+                    any = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NM_FUSED_FOREST_TREES; ++g) {
+            if (t0 + g >= F.n_trees) break;
+            const double* val = F.leaf_value + (int64_t)(rec[g].y & 0x7FFFFFFFu) * F.n_classes;
+#pragma unroll
+            for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)
+                if (c < F.n_classes) acc[c] += val[c];
+        }
+    }
+    int best = 0;
+    double bestv = -1.0;
+#pragma unroll
+    for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c) {
+        if (c < F.n_classes) {
+            const double pr = acc[c] / (double)F.n_trees;
+            if (F.proba) F.proba[(int64_t)qi * F.pstride + c] = pr;
+            if (pr > bestv) {   // first maximum wins, like numpy.argmax
+                bestv = pr;
+                best = c;
+            }
+        }
+    }
+    if (F.label) F.label[qi] = best;
+}
+
+// LOOP = false: exactly one scale per launch (A.s_begin) - the form every register count in DESIGN.md is
+// quoted for.  LOOP = true: the wave walks the scales [A.s_begin, A.s_end).
+template <int W, bool RHO3, bool FOREST, bool LOOP>
+__global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTable RT,
+                                                       const ScaleDev* __restrict__ scales)
 {
     static_assert(W >= 3 && W <= 9 && (W & 1), "LUT kernel covers W = 3,5,7,9");
     static_assert(!RHO3 || W == 7, "the compile-time table is for W = 7");
     constexpr int C = (W - 1) / 2;
     constexpr int ROWS_PER_REG = 30 / W;                          // packed mask fields per VGPR, from bit 2
     constexpr int MASK_REGS = (W * W + ROWS_PER_REG - 1) / ROWS_PER_REG;
-    __shared__ uint64_t rows[ROWS_CAP];
-    __shared__ int32_t sbt[SBT_CAP];
-    __shared__ uint32_t lut[1 << W];
+    // one block of LDS: the staged rows, the superblock table and the moment table; the classifier's
+    // feature stage reuses all of it after the last scale
+    constexpr int SEARCH_BYTES = ROWS_CAP * 8 + SBT_CAP * 4 + (4 << W);
+    constexpr int STAGE_BYTES = FOREST ? NM_FUSED_FOREST_FEATURES * 64 * 4 : 0;   // = SEARCH_BYTES at W = 7
+    constexpr int LDS_BYTES = SEARCH_BYTES > STAGE_BYTES ? SEARCH_BYTES : STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    uint64_t* rows = (uint64_t*)lds_raw;
+    int32_t* sbt = (int32_t*)(lds_raw + ROWS_CAP * 8);
+    uint32_t* lut = (uint32_t*)(lds_raw + ROWS_CAP * 8 + SBT_CAP * 4);
 
     const int lane = threadIdx.x;
-    const LatticeDev& L = A.L;
     const int32_t dmin = A.dmin;
     const int32_t dmax = dmin + W - 1;
 
-
     const int64_t batch = nm_xcd_batch(blockIdx.x, gridDim.x);
+    // the moment table comes from constant data (computing it cost every wave ~70 vector instructions)
+    for (int m = lane; m < (1 << W); m += 64) lut[m] = NM_LUT<W>.v[m];
+
+    // every scale of this launch in turn: the wave keeps its 64 queries.  nothing per-lane is carried from
+    // one scale to the next in registers - the query is read again (from L1/L2 now) - so that the loop costs
+    // no registers over the one-scale kernel
+#pragma nounroll
+    for (int32_t s = A.s_begin; s < (LOOP ? A.s_end : A.s_begin + 1); ++s) {
     const int64_t slot = batch * 64 + lane;
     bool have = slot < A.n_slots;
     uint32_t qi = 0;
@@ -581,6 +744,16 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         qy = p[1];
         qz = p[2];
     }
+    // (the scale array is a kernel parameter of its own, restrict-qualified: the compiler can then prove
+    // that nothing in the kernel writes it and reads it with scalar loads into SGPRs)
+    const ScaleDev* __restrict__ S = scales + s;
+    if (!S->valid) continue;                 // reported through the context's status words
+    const LatticeDev L = S->L;
+    const IndexDev I = S->I;
+    const double r2 = S->r2;
+    // coordinates too large for the static window bounds: this scale is left to k_scale_features_fallback
+    // (keeping the per-lane walk out of this kernel keeps its registers at 80)
+    if (!S->prune_ok) continue;
     const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
     const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
     const int32_t hz = nm_clamp_cell(nm_cell_f(qz, L.min_z, L.edge));
@@ -589,17 +762,17 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                      hy + dmin >= (1 << L.wy) || hz + dmax < 0 || hz + dmin >= (1 << L.wz);
     bool done = !have || far;
     if (have && far) {
-        double* o = A.feat + (int64_t)qi * A.fstride;
+        double* o = A.feat + (int64_t)qi * A.fstride + 4 * s;
         o[0] = 0.0;
         o[1] = 0.0;
         o[2] = 0.0;
         o[3] = 0.0;
         if (A.cov) {
-            double* c = A.cov + (int64_t)qi * A.cstride;
+            double* c = A.cov + (int64_t)qi * A.cstride + 6 * s;
             c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = 0.0;
         }
         if (A.normal) {
-            double* v = A.normal + (int64_t)qi * A.nstride;
+            double* v = A.normal + (int64_t)qi * A.nstride + 3 * s;
             v[0] = v[1] = v[2] = 0.0;
         }
     }
@@ -614,6 +787,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
     const bool tab = NM_CENTRE_TABLE && blox <= bhix && (int64_t)bhix - blox + W <= 64 &&
                      (int64_t)bhiy - bloy + W <= 64 && (int64_t)bhiz - bloz + W <= 64;
     double* ctab = (double*)rows;      // 3 x 64 doubles; the row buffer is not in use yet
+    lds_fence();                       // the previous scale's last pass has read the row buffer
     if (tab) {
         ctab[lane] = nm_centre(blox + dmin + lane, L.min_x, L.edge, L.half_edge);
         ctab[64 + lane] = nm_centre(bloy + dmin + lane, L.min_y, L.edge, L.half_edge);
@@ -630,8 +804,8 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
     const int32_t sgn_y = uy_home < 0.0 ? -1 : 1;
     const int32_t sgn_z = uz_home < 0.0 ? -1 : 1;
 
-    // ---- phase A (once per wave): the inside/outside bit of every candidate that needs a test, as
-    //      W-bit row masks packed ROWS_PER_REG to a register.  independent of the occupancy.
+    // ---- phase A (once per wave and scale): the inside/outside bit of every candidate that needs a test,
+    //      as W-bit row masks packed ROWS_PER_REG to a register.  independent of the occupancy.
     uint32_t inside[MASK_REGS];
     {
         // squared coordinate differences to the W candidate centres per axis (bit-identical centres)
@@ -682,8 +856,8 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
                     if (ad <= rb.a) {
                         outside = outside << 1;
                     } else {
-                        const double s = pxy[i] + dz2[k];
-                        const double t = A.r2 - s;     // sign bit set  <=>  s > r^2  (exact)
+                        const double sq = pxy[i] + dz2[k];
+                        const double t = r2 - sq;      // sign bit set  <=>  sq > r^2  (exact)
                         outside = __builtin_amdgcn_alignbit(outside, (uint32_t)__double2hiint(t), 31);
                     }
                 }
@@ -697,8 +871,6 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // the moment table comes from constant data (computing it cost every wave ~70 vector instructions)
-    for (int m = lane; m < (1 << W); m += 64) lut[m] = NM_LUT<W>.v[m];
     lds_fence();
 
     uint32_t m_n = 0, m_sx = 0, m_sy = 0, m_sz = 0, m_sxx = 0, m_sxy = 0, m_sxz = 0, m_syy = 0,
@@ -758,7 +930,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
             int32_t sx = sbx0 + ix, sy = sby0 + iy, sz = sbz0 + (int32_t)iz;
             bool ok = sx >= 0 && sy >= 0 && sz >= 0 && sx < (1 << L.bx) && sy < (1 << L.by) &&
                       sz < (1 << L.bz);
-            sbt[t] = ok ? nm_hash_find(A.I, nm_sb_key((uint32_t)sx, (uint32_t)sy, (uint32_t)sz, L))
+            sbt[t] = ok ? nm_hash_find(I, nm_sb_key((uint32_t)sx, (uint32_t)sy, (uint32_t)sz, L))
                         : -1;
         }
         lds_fence();
@@ -772,9 +944,9 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
             int32_t t0 = (((z >> NM_SBZ_BITS) - sbz0) * nsy + ((y >> NM_SBY_BITS) - sby0)) * 3;
             uint32_t wofs = (uint32_t)((z & 7) * 8 + (y & 7));
             int32_t l0 = sbt[t0], l1 = sbt[t0 + 1], l2 = sbt[t0 + 2];
-            uint32_t w0 = l0 >= 0 ? A.I.leaf[(size_t)l0 * NM_LEAF_WORDS + wofs] : 0u;
-            uint32_t w1 = l1 >= 0 ? A.I.leaf[(size_t)l1 * NM_LEAF_WORDS + wofs] : 0u;
-            uint32_t w2 = l2 >= 0 ? A.I.leaf[(size_t)l2 * NM_LEAF_WORDS + wofs] : 0u;
+            uint32_t w0 = l0 >= 0 ? I.leaf[(size_t)l0 * NM_LEAF_WORDS + wofs] : 0u;
+            uint32_t w1 = l1 >= 0 ? I.leaf[(size_t)l1 * NM_LEAF_WORDS + wofs] : 0u;
+            uint32_t w2 = l2 >= 0 ? I.leaf[(size_t)l2 * NM_LEAF_WORDS + wofs] : 0u;
             uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
             uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
             rows[rr] = (uint64_t)lo | ((uint64_t)hi << 32);
@@ -848,7 +1020,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         }
         lds_fence();
     }
-    if (passes > 1 && lane == 0) atomicAdd(&A.stats[1], passes - 1);
+    if (passes > 1 && lane == 0) atomicAdd(&I.counters[9], passes - 1);
 
     // ---- epilogue: features from the integer moments (features.py:21-57), one query per lane
     const bool emit = have && !far;
@@ -861,7 +1033,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
         nm_features_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
                                  (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
                                  (double)m_syz, (double)m_szz, ux, uy, uz, (double)dmin, L.edge, out);
-        double* o = A.feat + (int64_t)qi * A.fstride;
+        double* o = A.feat + (int64_t)qi * A.fstride + 4 * s;
         o[0] = out[0];
         o[1] = out[1];
         o[2] = out[2];
@@ -870,128 +1042,92 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
             nm_covariance_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
                                        (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
                                        (double)m_syz, (double)m_szz, (double)sgn_y, (double)sgn_z,
-                                       L.edge, A.cov + (int64_t)qi * A.cstride);
+                                       L.edge, A.cov + (int64_t)qi * A.cstride + 6 * s);
         if (A.normal)
             nm_normal_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz, (double)m_sxx,
                                    (double)m_sxy, (double)m_sxz, (double)m_syy, (double)m_syz,
                                    (double)m_szz, (double)sgn_y, (double)sgn_z,
-                                   A.normal + (int64_t)qi * A.nstride);
+                                   A.normal + (int64_t)qi * A.nstride + 3 * s);
     }
     const unsigned long long degenerate = __ballot(emit && m_n < 2u);
     if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
-        atomicAdd(&A.stats[0], (uint32_t)__popcll(degenerate));
+        atomicAdd(&I.counters[8], (uint32_t)__popcll(degenerate));
     if (A.sparse) {
         const unsigned long long sparse = __ballot(have && (far || m_n < (uint32_t)A.sparse_k));
-        if (lane == 0) A.sparse[batch] = sparse;
+        if (lane == 0) A.sparse[(int64_t)s * A.sparse_words + batch] = sparse;
+    }
+    }   // scale loop
+
+    if (FOREST) {
+        const int64_t slot = batch * 64 + lane;
+        bool have = slot < A.n_slots;
+        uint32_t qi = 0;
+        if (have) {
+            qi = A.order[slot];
+            have = qi < A.nq;
+        }
+        lds_fence();                         // the last pass has read the row buffer
+        nm_forest_epilogue(A, (float*)lds_raw, lane, have, qi);
     }
 }
 
 // ---- generic kernel: any W, direct index lookups per lane (no staging).  slow path for unusual
-//      radius/edge ratios; same arithmetic.
+//      radius/edge ratios; same arithmetic.  ONLY_UNPRUNED: the companion of the table kernels, a small
+//      persistent grid that handles exactly the scales they skip (lattices whose coordinates are too large
+//      for the static window bounds) and otherwise leaves at once.
+template <bool ONLY_UNPRUNED>
 __global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
 {
-    const LatticeDev& L = A.L;
-    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (slot >= A.n_slots) return;
-    const uint32_t qi = A.order[slot];
-    if (qi >= A.nq) return;
-    const double* p = A.query + (A.direct ? slot : (int64_t)qi) * A.qstride;
-    const double qx = p[0], qy = p[1], qz = p[2];
-    const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
-    const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
-    const int32_t hz = nm_clamp_cell(nm_cell_f(qz, L.min_z, L.edge));
-    const int32_t W = A.W, dmin = A.dmin;
-    double n = 0, sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-    for (int32_t k = 0; k < W; ++k) {
-        const int32_t gz = hz + dmin + k;
-        if (gz < 0 || gz >= (1 << L.wz)) continue;
-        double d = qz - nm_centre(gz, L.min_z, L.edge, L.half_edge);
-        const double dz2 = d * d;
-        for (int32_t j = 0; j < W; ++j) {
-            const int32_t gy = hy + dmin + j;
-            if (gy < 0 || gy >= (1 << L.wy)) continue;
-            d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
-            const double dy2 = d * d;
-            int32_t cached_sb = INT32_MIN;
-            uint32_t word = 0;
-            for (int32_t i = 0; i < W; ++i) {
-                const int32_t gx = hx + dmin + i;
-                if (gx < 0 || gx >= (1 << L.wx)) continue;
-                const int32_t sbx = gx >> NM_SBX_BITS;
-                if (sbx != cached_sb) {
-                    cached_sb = sbx;
-                    int32_t leaf = nm_hash_find(
-                        A.I, nm_sb_key((uint32_t)sbx, (uint32_t)(gy >> NM_SBY_BITS),
-                                       (uint32_t)(gz >> NM_SBZ_BITS), L));
-                    word = leaf >= 0 ? A.I.leaf[(size_t)leaf * NM_LEAF_WORDS + (gz & 7) * 8 + (gy & 7)]
-                                     : 0u;
-                }
-                if (!((word >> (gx & 31)) & 1u)) continue;
-                d = qx - nm_centre(gx, L.min_x, L.edge, L.half_edge);
-                const double s = (d * d + dy2) + dz2;
-                if (s <= A.r2) {
-                    n += 1.0;
-                    sx += i;
-                    sy += j;
-                    sz += k;
-                    sxx += (double)i * i;
-                    sxy += (double)i * j;
-                    sxz += (double)i * k;
-                    syy += (double)j * j;
-                    syz += (double)j * k;
-                    szz += (double)k * k;
-                }
+    if (ONLY_UNPRUNED) {
+        bool any = false;
+        for (int32_t s = A.s_begin; s < A.s_end; ++s)
+            any = any || (A.scales[s].valid && !A.scales[s].prune_ok);
+        if (!any) return;
+    }
+    const int64_t n_batches = (A.n_slots + 63) / 64;
+    for (int64_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+        const int64_t slot = batch * 64 + threadIdx.x;
+        bool have = slot < A.n_slots;
+        uint32_t qi = 0;
+        if (have) {
+            qi = A.order[slot];
+            have = qi < A.nq;
+        }
+        double qx = 0.0, qy = 0.0, qz = 0.0;
+        if (have) {
+            const double* p = A.query + (A.direct ? slot : (int64_t)qi) * A.qstride;
+            qx = p[0];
+            qy = p[1];
+            qz = p[2];
+        }
+        for (int32_t s = A.s_begin; s < A.s_end; ++s) {
+            const ScaleDev* __restrict__ S = A.scales + s;
+            if (!S->valid || (ONLY_UNPRUNED && S->prune_ok)) continue;
+            bool sp = false;
+            if (have) nm_lane_generic(A, S->L, S->I, S->r2, s, qi, qx, qy, qz, &sp);
+            if (A.sparse) {
+                const unsigned long long sparse = __ballot(have && sp);
+                if (threadIdx.x == 0) A.sparse[(int64_t)s * A.sparse_words + batch] = sparse;
             }
         }
     }
-    double out[4];
-    const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
-    const double uy = qy - nm_centre(hy, L.min_y, L.edge, L.half_edge);
-    const double uz = qz - nm_centre(hz, L.min_z, L.edge, L.half_edge);
-    nm_features_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, ux, uy, uz, (double)dmin,
-                             L.edge, out);
-    double* o = A.feat + (int64_t)qi * A.fstride;
-    o[0] = out[0];
-    o[1] = out[1];
-    o[2] = out[2];
-    o[3] = out[3];
-    if (A.cov)
-        nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
-                                   A.cov + (int64_t)qi * A.cstride);
-    if (A.normal)
-        nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0,
-                               A.normal + (int64_t)qi * A.nstride);
-    if (n < 2.0) atomicAdd(&A.stats[0], 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
 
-__global__ void k_publish_info(const uint32_t* counters, int64_t* info)
-{
-    if (threadIdx.x == 0) {
-        info[0] = counters[3] ? -1 : (int64_t)counters[1];   // M (-1: the index build timed out)
-        info[1] = counters[8];   // neighborhoods with population < 2
-        info[2] = counters[9];   // extra passes of the search kernel
-        info[3] = counters[0];   // leaves
-    }
-}
-
-struct PublishList {
-    int32_t n;
-    const uint32_t* counters[NM_MAX_LADDER];
-};
-
-__global__ void k_publish_info_all(PublishList P, int64_t* info)
+__global__ void k_publish_info_all(const ScaleDev* __restrict__ ladder, int32_t n, int64_t* info)
 {
     const int i = threadIdx.x;
-    if (i < P.n) {
-        const uint32_t* counters = P.counters[i];
-        info[4 * i + 0] = counters[3] ? -1 : (int64_t)counters[1];
-        info[4 * i + 1] = counters[8];
-        info[4 * i + 2] = counters[9];
-        info[4 * i + 3] = counters[0];
+    if (i < n) {
+        const uint32_t* counters = ladder[i].I.counters;
+        // M (-1: the index build timed out or overflowed, or the lattice is not addressable)
+        const bool bad = !ladder[i].valid || counters[3] || counters[2];
+        info[4 * i + 0] = bad ? -1 : (int64_t)counters[1];
+        info[4 * i + 1] = counters[8];   // neighborhoods with population < 2
+        info[4 * i + 2] = counters[9];   // extra passes of the search kernel
+        info[4 * i + 3] = counters[0];   // leaves
     }
 }
 
@@ -1004,25 +1140,13 @@ constexpr int NM_KNN_MAX = 16;
 
 struct KnnArgs {
     ScaleArgs S;
+    int32_t scale;             // which scale of S.scales
     int32_t k;
     double rk2;
     int32_t max_shell;
     const uint32_t* list;      // slots whose population is below k, compacted
     const uint32_t* count;
 };
-
-// the sparse bits of the generic kernel's slots (the table kernels write theirs on the way)
-__global__ __launch_bounds__(64) void k_knn_mark(ScaleArgs A)
-{
-    const int64_t slot = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    bool sparse = false;
-    if (slot < A.n_slots) {
-        const uint32_t qi = A.order[slot];
-        if (qi < A.nq) sparse = A.feat[(int64_t)qi * A.fstride] < (double)A.sparse_k;
-    }
-    const unsigned long long m = __ballot(sparse);
-    if (threadIdx.x == 0) A.sparse[blockIdx.x] = m;
-}
 
 // bits -> list of slots.  one counter atomic per block of 256 words (16 k slots)
 __global__ __launch_bounds__(256) void k_knn_compact(const unsigned long long* __restrict__ mask,
@@ -1063,13 +1187,16 @@ __global__ __launch_bounds__(256) void k_knn_compact(const unsigned long long* _
 __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
 {
     const ScaleArgs& A = K.S;
-    const LatticeDev& L = A.L;
+    const ScaleDev* __restrict__ SD = A.scales + K.scale;
+    if (!SD->valid) return;
+    const LatticeDev L = SD->L;
+    const IndexDev I = SD->I;
     // the launch covers every slot; the waves beyond the list leave at once
     const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (idx >= (int64_t)*K.count) return;
     const int64_t slot = K.list[idx];
     const uint32_t qi = A.order[slot];
-    double* o = A.feat + (int64_t)qi * A.fstride;
+    double* o = A.feat + (int64_t)qi * A.fstride + 4 * K.scale;
     const double* p = A.query + (A.direct ? slot : (int64_t)qi) * A.qstride;
     const double qx = p[0], qy = p[1], qz = p[2];
     const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
@@ -1103,7 +1230,7 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
         for (int32_t sby = y_lo >> NM_SBY_BITS; sby <= (y_hi >> NM_SBY_BITS); ++sby)
             for (int32_t sbx = x_lo >> NM_SBX_BITS; sbx <= (x_hi >> NM_SBX_BITS); ++sbx) {
                 const int32_t leaf = nm_hash_find(
-                    A.I, nm_sb_key((uint32_t)sbx, (uint32_t)sby, (uint32_t)sbz, L));
+                    I, nm_sb_key((uint32_t)sbx, (uint32_t)sby, (uint32_t)sbz, L));
                 if (leaf < 0) continue;
                 // bits of this leaf's 32 x-cells that lie inside [x_lo, x_hi]
                 const int32_t bx0 = sbx << NM_SBX_BITS;
@@ -1117,7 +1244,7 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
                     for (int32_t ly = 0; ly < 8; ++ly) {
                         const int32_t gy = (sby << NM_SBY_BITS) + ly;
                         if (gy < y_lo || gy > y_hi) continue;
-                        uint32_t word = A.I.leaf[(size_t)leaf * NM_LEAF_WORDS + lz * 8 + ly] & xmask;
+                        uint32_t word = I.leaf[(size_t)leaf * NM_LEAF_WORDS + lz * 8 + ly] & xmask;
                         if (!word) continue;
                         d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
                         const double dy2 = d * d;
@@ -1182,52 +1309,56 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
     o[3] = out[3];
     if (A.cov)
         nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
-                                   A.cov + (int64_t)qi * A.cstride);
+                                   A.cov + (int64_t)qi * A.cstride + 6 * K.scale);
     if (A.normal)
         nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0,
-                               A.normal + (int64_t)qi * A.nstride);
+                               A.normal + (int64_t)qi * A.nstride + 3 * K.scale);
 }
 
-// workspace of the fallback: the sparse bits, the compacted slots, their count
+// workspace of the fallback: the sparse bits (one mask per scale), the compacted slots, their count
 struct KnnLayout {
-    size_t mask, list, count, total;
+    size_t mask, list, count;
+    int64_t words;           // 64-bit words of one scale's mask
 };
 
-static void knn_layout(int64_t n_slots, size_t* off, KnnLayout* Kl)
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+static void knn_layout(int64_t n_slots, int n_scales, size_t* off, KnnLayout* Kl)
 {
     auto take = [&](size_t bytes) {
         size_t at = *off;
-        *off += (bytes + 255) / 256 * 256;
+        *off += align_up(bytes);
         return at;
     };
-    Kl->mask = take((size_t)((n_slots + 63) / 64) * 8);
+    Kl->words = (n_slots + 63) / 64;
+    Kl->mask = take((size_t)Kl->words * 8 * (size_t)n_scales);
     Kl->list = take((size_t)n_slots * 4);
     Kl->count = take(256);
 }
 
-static int launch_knn_fallback(nm_ctx* ctx, const ScaleArgs& A, double radius, bool marked,
+// re-evaluates the sparse rows of scale `scale` (their bits were left by the search kernel)
+static int launch_knn_fallback(nm_ctx* ctx, const ScaleArgs& A, int scale, double radius, double edge,
                                uint32_t* list, uint32_t* count, hipStream_t s)
 {
     if (ctx->knn_k <= 0 || A.nq <= 0) return NM_OK;
     const int64_t n_words = (A.n_slots + 63) / 64;
-    if (!marked) k_knn_mark<<<(int)n_words, 64, 0, s>>>(A);
     NM_HIP(ctx, hipMemsetAsync(count, 0, 4, s));
-    k_knn_compact<<<(int)((n_words + 255) / 256), 256, 0, s>>>(A.sparse, n_words, list, count);
+    k_knn_compact<<<(int)((n_words + 255) / 256), 256, 0, s>>>(A.sparse + (int64_t)scale * A.sparse_words,
+                                                               n_words, list, count);
     KnnArgs K;
     K.S = A;
+    K.scale = scale;
     K.list = list;
     K.count = count;
     K.k = ctx->knn_k;
     const double rk = radius * ctx->knn_radius_factor;
     K.rk2 = rk * rk;
-    double shells = ceil(rk / A.L.edge + 0.5);
+    double shells = ceil(rk / edge + 0.5);
     if (shells > 1000.0) shells = 1000.0;
     K.max_shell = (int32_t)shells;
     k_knn_fallback<<<(int)((A.n_slots + 63) / 64), 64, 0, s>>>(K);
     return NM_OK;
 }
-
-static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // candidates per axis: all integer offsets d with |d + 1/2 - f| <= r/e for some f in [0,1), with a
 // guard for rounding in r/e.  a superset is harmless: every candidate is tested exactly.
@@ -1240,39 +1371,46 @@ static int candidate_width(double radius, double edge, int32_t* dmin)
     return 2 * (int32_t)m + 1;
 }
 
-// picks the kernel instance for (W, r/e) and launches it
-// returns true if the kernel it chose writes the sparse bits of the kNN fallback itself
-static bool launch_scale_kernel(const ScaleArgs& A, const nm_lattice* lat, double radius, int W,
+// picks the kernel instance for (W, r/e) and launches it for the scales [A.s_begin, A.s_end), which all
+// share that window; `forest`: evaluate A.F behind the last of them (table kernels only)
+template <bool FOREST, bool LOOP>
+static void launch_table_kernel(const ScaleArgs& A, double rho, int W, int blocks, hipStream_t s)
+{
+    const double rho2 = rho * rho;
+    // whether pruning is sound for a lattice is decided on the device (ScaleDev::prune_ok): the tables
+    // here are the pruned ones, lattices that cannot use them take the per-lane path inside the kernel
+    const bool rho3 = W == 7 && fabs(rho - 3.0) < 1e-9;
+    switch (W) {
+        case 3: k_scale_features<3, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, true), A.scales); break;
+        case 5: k_scale_features<5, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, true), A.scales); break;
+        case 7:
+            if (rho3) k_scale_features<7, true, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3, A.scales);
+            else k_scale_features<7, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, true), A.scales);
+            break;
+        default: k_scale_features<9, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, true), A.scales); break;
+    }
+}
+
+// returns true when the forest (if asked for) was evaluated by the launch
+static bool launch_scale_kernel(const ScaleArgs& A, double radius, double edge, int W, bool forest,
                                 hipStream_t s)
 {
     // one workgroup per 64-query batch: the hardware dispatcher balances the uneven batches (waves
     // that need several passes) better than a persistent grid did (measured: persistent -17 %)
     const int blocks = (int)((A.n_slots + 63) / 64);
-    const int generic_blocks = blocks;
-    // static pruning of the candidate window is sound only while the rounding of cells and centres
-    // stays far below the 1e-4-cell padding of the bounds: 16 ulp of the largest coordinate the
-    // lattice can produce must be smaller than that.
-    double maxabs = 0.0;
-    for (int a = 0; a < 3; ++a) {
-        const double lo = lat->min_corner[a];
-        const double hi = lo + ldexp(lat->edge, lat->widths[a]);
-        maxabs = fmax(maxabs, fmax(fabs(lo), fabs(hi)));
+    const double rho = radius / edge;
+    if (W == 3 || W == 5 || W == 7 || W == 9) {
+        // the scales the table kernel has to skip (decided on the device) first: the classifier in the
+        // table kernel's epilogue needs every column of the row
+        k_scale_features_generic<true><<<blocks < 2048 ? blocks : 2048, 64, 0, s>>>(A);
+        const bool loop = A.s_end - A.s_begin > 1;
+        if (forest) launch_table_kernel<true, true>(A, rho, W, blocks, s);
+        else if (loop) launch_table_kernel<false, true>(A, rho, W, blocks, s);
+        else launch_table_kernel<false, false>(A, rho, W, blocks, s);
+        return forest;
     }
-    const bool prune = 16.0 * maxabs * 2.220446049250313e-16 < 1e-4 * lat->edge;
-    const double rho = radius / lat->edge;
-    const double rho2 = rho * rho;
-    const bool rho3 = prune && W == 7 && fabs(rho - 3.0) < 1e-9;
-    switch (W) {
-        case 3: k_scale_features<3, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, prune)); break;
-        case 5: k_scale_features<5, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, prune)); break;
-        case 7:
-            if (rho3) k_scale_features<7, true><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3);
-            else k_scale_features<7, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, prune));
-            break;
-        case 9: k_scale_features<9, false><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, prune)); break;
-        default: k_scale_features_generic<<<generic_blocks, 64, 0, s>>>(A); return false;
-    }
-    return true;
+    k_scale_features_generic<false><<<blocks, 64, 0, s>>>(A);
+    return false;
 }
 
 static int check_scale_args(nm_ctx* ctx, const char* who, const double* d_query, int64_t n_query,
@@ -1288,6 +1426,16 @@ static int check_scale_args(nm_ctx* ctx, const char* who, const double* d_query,
     return NM_OK;
 }
 
+static void fill_outputs(nm_ctx* ctx, ScaleArgs* A)
+{
+    A->cov = ctx->cov_out;
+    A->cstride = ctx->cov_stride;
+    A->normal = ctx->normal_out;
+    A->nstride = ctx->normal_stride;
+    A->sparse_k = ctx->knn_k;
+    A->F = ForestDev{};
+}
+
 // ---- one scale, self-contained (sorts at this scale) ----------------------------------------------------
 
 struct ScaleLayout {
@@ -1295,6 +1443,7 @@ struct ScaleLayout {
     size_t qkey_tmp, qval_tmp, qkey_sorted, qval_sorted;
     size_t sort_temp, sort_temp_bytes;
     size_t index;
+    size_t scale_dev;                                  // the one ScaleDev the search kernel reads
     IndexLayout ilay;
     KnnLayout knn;
     size_t total;
@@ -1324,7 +1473,8 @@ static void scale_layout(int64_t nq, int64_t ns, const LatticeDev& L, bool share
     S->sort_temp = take(S->sort_temp_bytes);
     nm_index_layout(L, ns, &S->ilay);
     S->index = take(S->ilay.total);
-    knn_layout(ns > nq ? ns : nq, &off, &S->knn);
+    S->scale_dev = take(sizeof(ScaleDev));
+    knn_layout(ns > nq ? ns : nq, 1, &off, &S->knn);
     S->total = off;
 }
 
@@ -1369,7 +1519,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)d_work;
 
-    // profile stages are [keys+sort | index | fused kernel]: four marks per call.  with a separate
+    // profile stages are [keys+sort | index | search kernel]: four marks per call.  with a separate
     // query cloud both sorts and the index are booked together under the first stage.
     nm_profile_mark(ctx, s);
     rc = nm_sort_cells(ctx, d_search, n_search, search_stride, L, (uint64_t*)(w + S.key_tmp),
@@ -1380,6 +1530,9 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
     IndexDev I;
     rc = nm_index_build(ctx, (const uint64_t*)(w + S.key_sorted), n_search, S.ilay, w + S.index, &I,
                         s);
+    if (rc) return rc;
+    ScaleDev* d_scale = (ScaleDev*)(w + S.scale_dev);
+    rc = nm_ladder_put(ctx, &L, &I, &radius, 1, -1, d_scale, nullptr, s);
     if (rc) return rc;
 
     const uint32_t* order = (const uint32_t*)(w + S.val_sorted);
@@ -1401,47 +1554,50 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
         A.qstride = query_stride;
         A.order = order;
         A.direct = 0;
-        A.L = L;
-        A.I = I;
-        A.r2 = radius * radius;
+        A.scales = d_scale;
+        A.s_begin = 0;
+        A.s_end = 1;
         A.dmin = dmin;
         A.W = W;
         A.feat = d_feat;
         A.fstride = feat_stride;
-        A.stats = I.counters + 8;
+        fill_outputs(ctx, &A);
         A.sparse = ctx->knn_k > 0 ? (unsigned long long*)(w + S.knn.mask) : nullptr;
-        A.sparse_k = ctx->knn_k;
-        A.cov = ctx->cov_out;
-        A.cstride = ctx->cov_stride;
-        A.normal = ctx->normal_out;
-        A.nstride = ctx->normal_stride;
-        const bool marked = launch_scale_kernel(A, lat, radius, W, s);
-        rc = launch_knn_fallback(ctx, A, radius, marked, (uint32_t*)(w + S.knn.list),
+        A.sparse_words = S.knn.words;
+        launch_scale_kernel(A, radius, lat->edge, W, false, s);
+        ctx->profile_launches += 1;
+        rc = launch_knn_fallback(ctx, A, 0, radius, lat->edge, (uint32_t*)(w + S.knn.list),
                                  (uint32_t*)(w + S.knn.count), s);
         if (rc) return rc;
     }
     nm_profile_mark(ctx, s);
     NM_HIP(ctx, hipGetLastError());
-    if (d_info) k_publish_info<<<1, 64, 0, s>>>(I.counters, d_info);
+    if (d_info) k_publish_info_all<<<1, 64, 0, s>>>(d_scale, 1, d_info);
     nm_status_snapshot(ctx, s);
     return NM_OK;
 }
 
 // ---- the whole ladder: one spatial order for every scale ----------------------------------------------
+// the workspace depends on the point counts and the number of scales only - not on the lattices, which
+// may not exist on the host at all (nm_ladder_features builds them on the device): every scale gets room
+// for as many leaves as there are search points and a directory twice that, and uses what its lattice
+// needs (min(superblocks of the lattice, points) leaves).
 
 struct LadderLayout {
     // per cloud: sort scratch, the order and the coordinates in that order
     size_t s_key_tmp, s_val_tmp, s_key, s_order, s_xyz;
     size_t q_key_tmp, q_val_tmp, q_key, q_order, q_xyz;
     size_t sort_temp, sort_temp_bytes;
-    size_t index[NM_MAX_LADDER];     // one index per scale: they are cleared and counted together
-    IndexLayout ilay[NM_MAX_LADDER];
+    size_t minmax;                   // 6 doubles: the search cloud's extrema
+    size_t ladder;                   // ScaleDev[n_scales]
+    size_t order_dev;                // OrderDev
+    size_t hash[NM_MAX_LADDER], leaf[NM_MAX_LADDER], counters[NM_MAX_LADDER];
+    uint32_t hash_capacity, leaf_capacity;
     KnnLayout knn;
     size_t total;
 };
 
-static void ladder_layout(int64_t nq, int64_t ns, const nm_lattice* lats, int n_scales, bool shared,
-                          LadderLayout* S)
+static void ladder_layout(int64_t nq, int64_t ns, int n_scales, bool shared, bool knn, LadderLayout* S)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -1449,15 +1605,15 @@ static void ladder_layout(int64_t nq, int64_t ns, const nm_lattice* lats, int n_
         off += align_up(bytes);
         return at;
     };
-    S->s_key_tmp = take((size_t)ns * 8);
+    S->s_key_tmp = take((size_t)ns * 4);
     S->s_val_tmp = take((size_t)ns * 4);
-    S->s_key = take((size_t)ns * 8);
+    S->s_key = take((size_t)ns * 4);
     S->s_order = take((size_t)ns * 4);
     S->s_xyz = take((size_t)ns * 24);
     if (!shared) {
-        S->q_key_tmp = take((size_t)nq * 8);
+        S->q_key_tmp = take((size_t)nq * 4);
         S->q_val_tmp = take((size_t)nq * 4);
-        S->q_key = take((size_t)nq * 8);
+        S->q_key = take((size_t)nq * 4);
         S->q_order = take((size_t)nq * 4);
         S->q_xyz = take((size_t)nq * 24);
     } else {
@@ -1465,31 +1621,174 @@ static void ladder_layout(int64_t nq, int64_t ns, const nm_lattice* lats, int n_
     }
     S->sort_temp_bytes = nm_sort_pairs_temp_bytes(ns > nq ? ns : nq);
     S->sort_temp = take(S->sort_temp_bytes);
+    S->minmax = take(64);
+    S->ladder = take(sizeof(ScaleDev) * (size_t)NM_MAX_LADDER);
+    S->order_dev = take(sizeof(OrderDev));
+    uint64_t cap = (uint64_t)(ns > 1 ? ns : 1);
+    uint64_t hcap = 64;
+    while (hcap < cap * 2) hcap <<= 1;
+    S->leaf_capacity = (uint32_t)cap;
+    S->hash_capacity = (uint32_t)hcap;
     for (int i = 0; i < n_scales && i < NM_MAX_LADDER; ++i) {
-        nm_index_layout(make_lattice_dev(&lats[i]), ns, &S->ilay[i]);
-        S->index[i] = take(S->ilay[i].total);
+        S->hash[i] = take((size_t)hcap * sizeof(HashEntry));
+        S->leaf[i] = take((size_t)cap * NM_LEAF_WORDS * 4);
+        S->counters[i] = take(256);
     }
-    knn_layout(ns > nq ? ns : nq, &off, &S->knn);
+    if (knn) knn_layout(ns > nq ? ns : nq, n_scales, &off, &S->knn);
+    else S->knn = KnnLayout{0, 0, 0, 0};
     S->total = off;
 }
 
-static hipEvent_t ladder_event(nm_ctx* ctx, size_t i)
+extern "C" size_t nm_ladder_workspace_bytes(int64_t n_query, int64_t n_search, int32_t n_scales)
 {
-    while (ctx->sync_events.size() <= i) {
-        hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        ctx->sync_events.push_back(e);
-    }
-    return ctx->sync_events[i];
+    if (n_scales < 1 || n_scales > NM_MAX_LADDER || n_query < 0 || n_search < 1) return 0;
+    LadderLayout S;
+    // sized for separate clouds and the kNN fallback so one workspace serves every mode
+    ladder_layout(n_query > 0 ? n_query : 1, n_search, n_scales, false, true, &S);
+    return S.total;
 }
 
 extern "C" size_t nm_multiscale_workspace_bytes(int64_t n_query, int64_t n_search,
                                                 const nm_lattice* lats, int32_t n_scales)
 {
-    if (!lats || n_scales < 1 || n_scales > NM_MAX_LADDER || n_query < 0 || n_search < 1) return 0;
-    LadderLayout S;
-    ladder_layout(n_query > 0 ? n_query : 1, n_search, lats, n_scales, false, &S);
-    return S.total;
+    if (!lats) return 0;
+    return nm_ladder_workspace_bytes(n_query, n_search, n_scales);
+}
+
+// what both ladder entry points do once the scale array is in device memory
+struct LadderCall {
+    const double* d_query; int64_t n_query, query_stride;
+    const double* d_search; int64_t n_search, search_stride;
+    const double* edges; const double* radii; int32_t n_scales;
+    double* d_feat; int64_t feat_stride; int64_t* d_info;
+    unsigned sort_bits;
+};
+
+static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, char* w, bool shared,
+                      hipStream_t s)
+{
+    const ScaleDev* d_ladder = (const ScaleDev*)(w + S.ladder);
+    const OrderDev* d_order = (const OrderDev*)(w + S.order_dev);
+    int rc = nm_order_build(ctx, C.d_search, C.n_search, C.search_stride, d_order, C.sort_bits,
+                            (uint32_t*)(w + S.s_key_tmp), (uint32_t*)(w + S.s_val_tmp),
+                            (uint32_t*)(w + S.s_key), (uint32_t*)(w + S.s_order), w + S.sort_temp,
+                            S.sort_temp_bytes, (double*)(w + S.s_xyz), s);
+    if (rc) return rc;
+    const uint32_t* q_order = (const uint32_t*)(w + S.s_order);
+    const double* q_xyz = (const double*)(w + S.s_xyz);
+    if (!shared && C.n_query > 0) {
+        rc = nm_order_build(ctx, C.d_query, C.n_query, C.query_stride, d_order, C.sort_bits,
+                            (uint32_t*)(w + S.q_key_tmp), (uint32_t*)(w + S.q_val_tmp),
+                            (uint32_t*)(w + S.q_key), (uint32_t*)(w + S.q_order), w + S.sort_temp,
+                            S.sort_temp_bytes, (double*)(w + S.q_xyz), s);
+        if (rc) return rc;
+        q_order = (const uint32_t*)(w + S.q_order);
+        q_xyz = (const double*)(w + S.q_xyz);
+    }
+    nm_profile_mark(ctx, s);           // end of the "order" stage
+    // every scale has its own index; one launch clears them all, one builds them all (the block keeps its
+    // points and walks the scales), one counts them all at the end
+    rc = nm_index_clear_all(ctx, d_ladder, C.n_scales, s);
+    if (rc) return rc;
+    rc = nm_index_build_ladder(ctx, (const double*)(w + S.s_xyz), C.n_search, d_ladder, 0, C.n_scales, s);
+    if (rc) return rc;
+    nm_profile_mark(ctx, s);           // end of the "index" stage
+
+    if (C.n_query > 0) {
+        ScaleArgs A;
+        A.query = q_xyz;
+        A.nq = C.n_query;
+        A.n_slots = shared ? C.n_search : C.n_query;
+        A.qstride = 3;
+        A.order = q_order;
+        A.direct = 1;
+        A.scales = d_ladder;
+        A.feat = C.d_feat;
+        A.fstride = C.feat_stride;
+        fill_outputs(ctx, &A);
+        A.sparse = ctx->knn_k > 0 ? (unsigned long long*)(w + S.knn.mask) : nullptr;
+        A.sparse_words = S.knn.words;
+        const bool want_forest = ctx->forest_on;
+        const bool in_kernel = want_forest && ctx->knn_k == 0;   // the fallback rewrites rows afterwards
+        bool forest_done = false;
+        if (want_forest) {
+            A.F = ctx->forest;
+            A.F.n_features = 4 * C.n_scales;
+        }
+        // consecutive scales with the same candidate window run in ONE launch (the wave keeps its queries
+        // and walks the scales): the benchmark ladder, r = 3e throughout, is a single launch
+        int i = 0;
+        while (i < C.n_scales) {
+            int32_t dmin = 0;
+            const int W = candidate_width(C.radii[i], C.edges[i], &dmin);
+            const double rho = C.radii[i] / C.edges[i];
+            int j = i + 1;
+            if (ctx->fuse_scales) {
+                while (j < C.n_scales) {
+                    int32_t dm2 = 0;
+                    const int W2 = candidate_width(C.radii[j], C.edges[j], &dm2);
+                    if (W2 != W || fabs(C.radii[j] / C.edges[j] - rho) > 1e-12 * rho) break;
+                    ++j;
+                }
+            }
+            A.s_begin = i;
+            A.s_end = j;
+            A.dmin = dmin;
+            A.W = W;
+            const bool last = j == C.n_scales;
+            forest_done = launch_scale_kernel(A, C.radii[i], C.edges[i], W, in_kernel && last, s);
+            ctx->profile_launches += 1;
+            for (int k = i; k < j; ++k) {
+                rc = launch_knn_fallback(ctx, A, k, C.radii[k], C.edges[k], (uint32_t*)(w + S.knn.list),
+                                         (uint32_t*)(w + S.knn.count), s);
+                if (rc) return rc;
+            }
+            i = j;
+        }
+        if (want_forest && !forest_done) {
+            // the last kernel could not carry the classifier (unusual window), or the kNN fallback has
+            // rewritten rows after it: evaluate on the finished matrix
+            rc = nm_forest_rows(ctx, ctx->forest, A.feat, A.fstride, A.nq, 4 * C.n_scales, s);
+            if (rc) return rc;
+        }
+    }
+    nm_profile_mark(ctx, s);           // end of the "search" stage
+    NM_HIP(ctx, hipGetLastError());
+    if (C.d_info) {
+        rc = nm_index_count_all(ctx, d_ladder, C.n_scales, s);
+        if (rc) return rc;
+        k_publish_info_all<<<1, 64, 0, s>>>(d_ladder, C.n_scales, C.d_info);
+        NM_HIP(ctx, hipGetLastError());
+    }
+    nm_status_snapshot(ctx, s);
+    return NM_OK;
+}
+
+static int check_ladder_args(nm_ctx* ctx, const char* who, int32_t n_scales, const double* edges,
+                             const double* radii, int64_t feat_stride, int* finest)
+{
+    if (n_scales > NM_MAX_LADDER)
+        NM_FAIL(ctx, NM_ERR_INVALID, "%s: at most %d scales per call", who, NM_MAX_LADDER);
+    if (feat_stride < 4 * (int64_t)n_scales)
+        NM_FAIL(ctx, NM_ERR_INVALID, "%s: feat_stride < 4 * n_scales", who);
+    if (ctx->cov_out && ctx->cov_stride < 6 * (int64_t)n_scales)
+        NM_FAIL(ctx, NM_ERR_INVALID, "%s: covariance stride < 6 * n_scales", who);
+    if (ctx->normal_out && ctx->normal_stride < 3 * (int64_t)n_scales)
+        NM_FAIL(ctx, NM_ERR_INVALID, "%s: normal stride < 3 * n_scales", who);
+    if (ctx->forest_on && ctx->forest_features != 4 * n_scales)
+        NM_FAIL(ctx, NM_ERR_INVALID, "%s: the forest takes %d features, the ladder makes %d", who,
+                ctx->forest_features, 4 * n_scales);
+    *finest = 0;
+    for (int i = 0; i < n_scales; ++i) {
+        if (!(edges[i] > 0.0)) NM_FAIL(ctx, NM_ERR_LATTICE, "edge length must be positive");
+        if (!(radii[i] >= 0.0)) NM_FAIL(ctx, NM_ERR_RADIUS, "radius must be non-negative");
+        int32_t dm;
+        if (candidate_width(radii[i], edges[i], &dm) < 0)
+            NM_FAIL(ctx, NM_ERR_RADIUS, "radius/edge ratio %g is outside the supported range",
+                    radii[i] / edges[i]);
+        if (edges[i] < edges[*finest]) *finest = i;
+    }
+    return NM_OK;
 }
 
 extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_t n_query,
@@ -1503,147 +1802,106 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
     if (n_scales < 0 || (n_scales > 0 && (!lats || !radii)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: bad scale arguments");
     if (n_scales == 0) return NM_OK;
-    if (n_scales > NM_MAX_LADDER)
-        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: at most %d scales per call", NM_MAX_LADDER);
-    if (feat_stride < 4 * (int64_t)n_scales)
-        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: feat_stride < 4 * n_scales");
-    if (ctx->cov_out && ctx->cov_stride < 6 * (int64_t)n_scales)
-        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: covariance stride < 6 * n_scales");
-    if (ctx->normal_out && ctx->normal_stride < 3 * (int64_t)n_scales)
-        NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: normal stride < 3 * n_scales");
-    int rc = check_scale_args(ctx, "nm_multiscale_features", d_query, n_query, query_stride, d_search,
-                              n_search, search_stride, d_feat, feat_stride, d_work);
-    if (rc) return rc;
+    double edges[NM_MAX_LADDER];
+    for (int i = 0; i < n_scales && i < NM_MAX_LADDER; ++i) edges[i] = lats[i].edge;
     int finest = 0;
+    int rc = check_ladder_args(ctx, "nm_multiscale_features", n_scales, edges, radii, feat_stride, &finest);
+    if (rc) return rc;
+    rc = check_scale_args(ctx, "nm_multiscale_features", d_query, n_query, query_stride, d_search,
+                          n_search, search_stride, d_feat, feat_stride, d_work);
+    if (rc) return rc;
     for (int i = 0; i < n_scales; ++i) {
         rc = validate_lattice(ctx, &lats[i]);
         if (rc) return rc;
-        if (!(radii[i] >= 0.0)) NM_FAIL(ctx, NM_ERR_RADIUS, "radius must be non-negative");
         if (make_lattice_dev(&lats[i]).keybits > 64)
             NM_FAIL(ctx, NM_ERR_LATTICE, "lattice too large for the device sort key");
-        int32_t dm;
-        if (candidate_width(radii[i], lats[i].edge, &dm) < 0)
-            NM_FAIL(ctx, NM_ERR_RADIUS, "radius/edge ratio %g is outside the supported range",
-                    radii[i] / lats[i].edge);
-        if (lats[i].edge < lats[finest].edge) finest = i;
     }
     const bool shared = (d_query == d_search && n_query <= n_search && n_query > 0 &&
                          query_stride == search_stride);
     LadderLayout S;
-    ladder_layout(n_query > 0 ? n_query : 1, n_search, lats, n_scales, shared, &S);
+    ladder_layout(n_query > 0 ? n_query : 1, n_search, n_scales, shared, ctx->knn_k > 0, &S);
     if (work_bytes < S.total)
         NM_FAIL(ctx, NM_ERR_WORKSPACE, "nm_multiscale_features: workspace %zu < required %zu",
                 work_bytes, S.total);
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)d_work;
-
-    // one spatial order per cloud, from the finest lattice of the ladder
-    const LatticeDev Lf = make_lattice_dev(&lats[finest]);
-    nm_profile_mark(ctx, s);   // first mark of scale 0: the order build is booked under its "keys"
-    rc = nm_order_build(ctx, d_search, n_search, search_stride, Lf, (uint64_t*)(w + S.s_key_tmp),
-                        (uint32_t*)(w + S.s_val_tmp), (uint64_t*)(w + S.s_key),
-                        (uint32_t*)(w + S.s_order), w + S.sort_temp, S.sort_temp_bytes,
-                        (double*)(w + S.s_xyz), s);
-    if (rc) return rc;
-    const uint32_t* q_order = (const uint32_t*)(w + S.s_order);
-    const double* q_xyz = (const double*)(w + S.s_xyz);
-    if (!shared && n_query > 0) {
-        rc = nm_order_build(ctx, d_query, n_query, query_stride, Lf, (uint64_t*)(w + S.q_key_tmp),
-                            (uint32_t*)(w + S.q_val_tmp), (uint64_t*)(w + S.q_key),
-                            (uint32_t*)(w + S.q_order), w + S.sort_temp, S.sort_temp_bytes,
-                            (double*)(w + S.q_xyz), s);
-        if (rc) return rc;
-        q_order = (const uint32_t*)(w + S.q_order);
-        q_xyz = (const double*)(w + S.q_xyz);
-    }
-
-    // every scale has its own index; all of them are cleared by one launch here and counted by one
-    // launch at the end
-    IndexDev index[NM_MAX_LADDER];
-    for (int i = 0; i < n_scales; ++i) index[i] = nm_index_at(ctx, w + S.index[i], S.ilay[i]);
-    rc = nm_index_clear_all(ctx, index, n_scales, s);
-    if (rc) return rc;
-
-    // pipelining: with overlap on (and profiling of the stages off) the index of scale i is built on
-    // the auxiliary stream while the caller's stream runs the kernel of scale i-1.
-    const bool overlap = ctx->overlap && n_scales > 1;
-    hipStream_t build = s;
-    if (overlap) {
-        if (!ctx->aux) {
-            // highest priority: the build kernels are short and memory/atomic bound; they must get
-            // dispatched between the workgroups of the long VALU-bound kernel, not behind them
-            int least = 0, greatest = 0;
-            NM_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            NM_HIP(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, greatest));
-        }
-        build = ctx->aux;
-        hipEvent_t ordered = ladder_event(ctx, 0);
-        if (!ordered) NM_FAIL(ctx, NM_ERR_HIP, "could not create a HIP event");
-        NM_HIP(ctx, hipEventRecord(ordered, s));
-        NM_HIP(ctx, hipStreamWaitEvent(build, ordered, 0));
-    }
+    nm_profile_mark(ctx, s);
+    // the host's lattices, with indexes sized for them, into the device array the kernels read
+    LatticeDev L[NM_MAX_LADDER];
+    IndexDev I[NM_MAX_LADDER];
     for (int i = 0; i < n_scales; ++i) {
-        const LatticeDev L = make_lattice_dev(&lats[i]);
-        int32_t dmin = 0;
-        const int W = candidate_width(radii[i], lats[i].edge, &dmin);
-        if (!overlap && i > 0) nm_profile_mark(ctx, s);
-        const bool was_profiling = ctx->profiling;
-        if (overlap) ctx->profiling = false;     // no stage marks on the auxiliary stream
-        const IndexDev I = index[i];
-        rc = nm_index_build_any(ctx, (const double*)(w + S.s_xyz), n_search, L, I, build);
-        ctx->profiling = was_profiling;
-        if (rc) return rc;
-        if (overlap) {
-            hipEvent_t built = ladder_event(ctx, 1 + 2 * i);
-            if (!built) NM_FAIL(ctx, NM_ERR_HIP, "could not create a HIP event");
-            NM_HIP(ctx, hipEventRecord(built, build));
-            NM_HIP(ctx, hipStreamWaitEvent(s, built, 0));
-            // keep four marks per scale: stages other than the kernel read as zero
-            if (i > 0) nm_profile_mark(ctx, s);
-            nm_profile_mark(ctx, s);
-        }
-        nm_profile_mark(ctx, s);
-        if (n_query > 0) {
-            ScaleArgs A;
-            A.query = q_xyz;
-            A.nq = n_query;
-            A.n_slots = shared ? n_search : n_query;
-            A.qstride = 3;
-            A.order = q_order;
-            A.direct = 1;
-            A.L = L;
-            A.I = I;
-            A.r2 = radii[i] * radii[i];
-            A.dmin = dmin;
-            A.W = W;
-            A.feat = d_feat + 4 * i;
-            A.fstride = feat_stride;
-            A.stats = I.counters + 8;
-            A.sparse = ctx->knn_k > 0 ? (unsigned long long*)(w + S.knn.mask) : nullptr;
-            A.sparse_k = ctx->knn_k;
-            A.cov = ctx->cov_out ? ctx->cov_out + 6 * i : nullptr;
-            A.cstride = ctx->cov_stride;
-            A.normal = ctx->normal_out ? ctx->normal_out + 3 * i : nullptr;
-            A.nstride = ctx->normal_stride;
-            const bool marked = launch_scale_kernel(A, &lats[i], radii[i], W, s);
-            rc = launch_knn_fallback(ctx, A, radii[i], marked, (uint32_t*)(w + S.knn.list),
-                                     (uint32_t*)(w + S.knn.count), s);
-            if (rc) return rc;
-        }
-        nm_profile_mark(ctx, s);
-        NM_HIP(ctx, hipGetLastError());
+        L[i] = make_lattice_dev(&lats[i]);
+        IndexLayout lay;
+        nm_index_layout(L[i], n_search, &lay);
+        I[i].hash = (HashEntry*)(w + S.hash[i]);
+        I[i].leaf = (uint32_t*)(w + S.leaf[i]);
+        I[i].counters = (uint32_t*)(w + S.counters[i]);
+        I[i].hash_mask = lay.hash_capacity - 1;
+        I[i].leaf_capacity = lay.leaf_capacity;
+        I[i].status = ctx->d_status;
     }
-    if (d_info) {
-        rc = nm_index_count_all(ctx, index, n_scales, s);
+    rc = nm_ladder_put(ctx, L, I, radii, n_scales, finest, (ScaleDev*)(w + S.ladder),
+                       (OrderDev*)(w + S.order_dev), s);
+    if (rc) return rc;
+    const LatticeDev& Lf = L[finest];
+    int wmax = Lf.wx > Lf.wy ? Lf.wx : Lf.wy;
+    if (Lf.wz > wmax) wmax = Lf.wz;
+    const int key_bits = wmax <= 21 ? Lf.wx + Lf.wy + Lf.wz : Lf.keybits;
+    LadderCall C{d_query, n_query, query_stride, d_search, n_search, search_stride, edges, radii,
+                 n_scales, d_feat, feat_stride, d_info, (unsigned)(key_bits > 32 ? 32 : key_bits)};
+    return run_ladder(ctx, C, S, w, shared, s);
+}
+
+// ---- the ladder with the lattices built on the device ----------------------------------------------------
+extern "C" int nm_ladder_features(nm_ctx* ctx, const double* d_query, int64_t n_query,
+                                  int64_t query_stride, const double* d_search, int64_t n_search,
+                                  int64_t search_stride, const double* edges, const double* radii,
+                                  int32_t n_scales, const double* d_minmax, double* d_feat,
+                                  int64_t feat_stride, int64_t* d_info, void* d_work, size_t work_bytes,
+                                  void* stream)
+{
+    NM_ENTER(ctx);
+    if (n_scales < 0 || (n_scales > 0 && (!edges || !radii)))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_ladder_features: bad scale arguments");
+    if (n_scales == 0) return NM_OK;
+    int finest = 0;
+    int rc = check_ladder_args(ctx, "nm_ladder_features", n_scales, edges, radii, feat_stride, &finest);
+    if (rc) return rc;
+    rc = check_scale_args(ctx, "nm_ladder_features", d_query, n_query, query_stride, d_search, n_search,
+                          search_stride, d_feat, feat_stride, d_work);
+    if (rc) return rc;
+    const bool shared = (d_query == d_search && n_query <= n_search && n_query > 0 &&
+                         query_stride == search_stride);
+    LadderLayout S;
+    ladder_layout(n_query > 0 ? n_query : 1, n_search, n_scales, shared, ctx->knn_k > 0, &S);
+    if (work_bytes < S.total)
+        NM_FAIL(ctx, NM_ERR_WORKSPACE, "nm_ladder_features: workspace %zu < required %zu", work_bytes,
+                S.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)d_work;
+    nm_profile_mark(ctx, s);
+    // the search cloud's extrema never leave the device: bounds pass (unless the caller has them, e.g. the
+    // global extrema of a multi-GPU job), then one tiny kernel turns them into every scale's lattice
+    const double* mm = d_minmax;
+    if (!mm) {
+        rc = nm_bounds(ctx, d_search, n_search, search_stride, (double*)(w + S.minmax), stream);
         if (rc) return rc;
-        PublishList P;
-        P.n = n_scales;
-        for (int i = 0; i < n_scales; ++i) P.counters[i] = index[i].counters;
-        k_publish_info_all<<<1, 64, 0, s>>>(P, d_info);
-        NM_HIP(ctx, hipGetLastError());
+        mm = (const double*)(w + S.minmax);
     }
-    nm_status_snapshot(ctx, s);
-    return NM_OK;
+    void* hash[NM_MAX_LADDER];
+    void* leaf[NM_MAX_LADDER];
+    void* counters[NM_MAX_LADDER];
+    for (int i = 0; i < n_scales; ++i) {
+        hash[i] = w + S.hash[i];
+        leaf[i] = w + S.leaf[i];
+        counters[i] = w + S.counters[i];
+    }
+    rc = nm_ladder_make(ctx, mm, edges, radii, n_scales, finest, hash, leaf, counters, S.hash_capacity,
+                        S.leaf_capacity, (ScaleDev*)(w + S.ladder), (OrderDev*)(w + S.order_dev), s);
+    if (rc) return rc;
+    LadderCall C{d_query, n_query, query_stride, d_search, n_search, search_stride, edges, radii,
+                 n_scales, d_feat, feat_stride, d_info, 32u};
+    return run_ladder(ctx, C, S, w, shared, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -20,18 +20,26 @@ int nm_sort_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, c
 int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const IndexLayout& lay,
                    void* index_mem, IndexDev* out, hipStream_t s);
 
-// whole-ladder path: one spatial order for all scales.
-// order[i] = original row of sorted slot i (sorted by the cell key of lattice L), sorted_xyz = the
-// coordinates in that order, (n,3) contiguous.
-int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const LatticeDev& L,
-                   uint64_t* key_tmp, uint32_t* val_tmp, uint64_t* key_sorted, uint32_t* order,
-                   void* sort_temp, size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
+// whole-ladder path: one spatial order for all scales, every scale described by a ScaleDev in device memory.
+// order[i] = original row of sorted slot i (sorted by the compact 32-bit cell key of the lattice in
+// *d_order_dev), sorted_xyz = the coordinates in that order, (n,3) contiguous.
+int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                   const OrderDev* d_order_dev, unsigned sort_bits, uint32_t* key_tmp,
+                   uint32_t* val_tmp, uint32_t* key_sorted, uint32_t* order, void* sort_temp,
+                   size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
 
-// ---- the ladder's indexes: one per scale, cleared and counted together --------------------------------
-constexpr int NM_MAX_LADDER = 32;     // scales per nm_multiscale_features call
+// the device-resident scale array: from host lattices, or from the cloud's extrema on the device
+int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const double* radii, int n_scales,
+                  int finest, ScaleDev* d_ladder, OrderDev* d_order, hipStream_t s);
+int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const double* edges, const double* radii,
+                   int n_scales, int finest, void* const* hash, void* const* leaf, void* const* counters,
+                   uint32_t hash_capacity, uint32_t leaf_capacity, ScaleDev* d_ladder, OrderDev* d_order,
+                   hipStream_t s);
+
+// ---- the ladder's indexes: one per scale, cleared, built and counted together ---------------------------
 IndexDev nm_index_at(nm_ctx* ctx, void* index_mem, const IndexLayout& lay);
-int nm_index_clear_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s);
-int nm_index_count_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s);
-// index of lattice L from a spatially coherent coordinate stream (no sort), into a cleared index
-int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
-                       const IndexDev& I, hipStream_t s);
+int nm_index_clear_all(nm_ctx* ctx, const ScaleDev* d_ladder, int n, hipStream_t s);
+int nm_index_count_all(nm_ctx* ctx, const ScaleDev* d_ladder, int n, hipStream_t s);
+// indexes of scales [first, first + count) from a spatially coherent coordinate stream (no sort)
+int nm_index_build_ladder(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const ScaleDev* d_ladder,
+                          int first, int count, hipStream_t s);

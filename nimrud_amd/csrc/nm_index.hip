@@ -628,7 +628,8 @@ constexpr int FUSED_TABLE_BITS = FUSED_ITERS == 16 ? 11 : (FUSED_ITERS == 8 ? 10
 static_assert(FUSED_ITERS % FUSED_GROUPS == 0 && (1 << FUSED_TABLE_BITS) == FUSED_TABLE, "fused build geometry");
 
 __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ xyz, int64_t n,
-                                                     LatticeDev L, IndexDev I)
+                                                     const ScaleDev* __restrict__ ladder,
+                                                     int32_t n_scales)
 {
     __shared__ uint32_t stash_slot[FUSED_CHUNK];     // table slot of the point's superblock
     __shared__ uint16_t stash_local[FUSED_CHUNK];    // the cell's 11 bits inside the superblock
@@ -640,187 +641,197 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
     uint32_t* won_slot = scratch;
     uint32_t* t_word = scratch;
     uint32_t* t_bits = scratch + FUSED_TABLE;
-    if (threadIdx.x == 0) won_count = 0u;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wave_lo = (int64_t)blockIdx.x * FUSED_CHUNK + (int64_t)w * FUSED_WAVE_KEYS;
-    const unsigned long long below = (2ull << lane) - 1ull;
+    // one launch builds every index of the ladder: the block keeps its 2048 points and walks the scales,
+    // so the coordinates of the coarser scales come out of the cache the finest one filled, and the
+    // launch has one ramp and one tail instead of one per scale
+#pragma nounroll
+    for (int32_t sc = 0; sc < n_scales; ++sc) {
+        if (!ladder[sc].valid) continue;
+        const LatticeDev L = ladder[sc].L;
+        const IndexDev I = ladder[sc].I;
+        __syncthreads();       // the previous scale's flush has read the scratch
+        if (threadIdx.x == 0) won_count = 0u;
+        __syncthreads();
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int64_t wave_lo = (int64_t)blockIdx.x * FUSED_CHUNK + (int64_t)w * FUSED_WAVE_KEYS;
+        const unsigned long long below = (2ull << lane) - 1ull;
 
-    // ---- phase 1: keys, run heads into the table, every point's (slot, local) into the stash
-    uint64_t carry = ~0ull;          // superblock of the previous point of this wave; none at its start:
-    uint32_t carry_slot = 0u;        // the first point of a wave always probes
-    for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {
-        const int64_t base = wave_lo + (int64_t)it * 64;
-        if (base >= n) break;
-        uint64_t sb[FUSED_GROUPS];
-        uint32_t local[FUSED_GROUPS];
-        bool valid[FUSED_GROUPS], head[FUSED_GROUPS];
-        uint32_t slot[FUSED_GROUPS];
-        uint64_t peek[FUSED_GROUPS];
-#pragma unroll
-        for (int g = 0; g < FUSED_GROUPS; ++g) {
-            const int64_t i = base + g * 64 + lane;
-            valid[g] = i < n;
-            uint64_t k = ~0ull;
-            if (valid[g]) k = nm_point_key(xyz + i * 3, L);
-            sb[g] = k >> NM_LOCAL_BITS;
-            local[g] = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
-            uint64_t prev = __shfl_up(sb[g], 1);
-            if (lane == 0) prev = carry;
-            carry = __shfl(sb[g], 63);
-            head[g] = valid[g] && sb[g] != prev;
-        }
-#pragma unroll
-        for (int g = 0; g < FUSED_GROUPS; ++g) {
-            slot[g] = nm_hash64(sb[g]) & I.hash_mask;
-            peek[g] = head[g] ? I.hash[slot[g]].key : sb[g];
-        }
-#pragma unroll
-        for (int g = 0; g < FUSED_GROUPS; ++g) {
-            if (!head[g] || peek[g] == sb[g]) continue;      // already in the table, at slot[g]
-            uint32_t sl = slot[g];
-            uint64_t pk = peek[g];
-            for (;;) {
-                if (pk == sb[g]) break;
-                if (pk != NM_HASH_EMPTY) {
-                    sl = (sl + 1) & I.hash_mask;
-                    pk = I.hash[sl].key;
-                    continue;
-                }
-                const unsigned long long seen =
-                    atomicCAS((unsigned long long*)&I.hash[sl].key,
-                              (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb[g]);
-                if (seen == NM_HASH_EMPTY) {
-                    won_slot[atomicAdd(&won_count, 1u)] = sl;
-                    break;
-                }
-                if (seen == sb[g]) break;
-                sl = (sl + 1) & I.hash_mask;
-                pk = I.hash[sl].key;
+        // ---- phase 1: keys, run heads into the table, every point's (slot, local) into the stash
+        uint64_t carry = ~0ull;          // superblock of the previous point of this wave; none at its start:
+        uint32_t carry_slot = 0u;        // the first point of a wave always probes
+        for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {
+            const int64_t base = wave_lo + (int64_t)it * 64;
+            if (base >= n) break;
+            uint64_t sb[FUSED_GROUPS];
+            uint32_t local[FUSED_GROUPS];
+            bool valid[FUSED_GROUPS], head[FUSED_GROUPS];
+            uint32_t slot[FUSED_GROUPS];
+            uint64_t peek[FUSED_GROUPS];
+    #pragma unroll
+            for (int g = 0; g < FUSED_GROUPS; ++g) {
+                const int64_t i = base + g * 64 + lane;
+                valid[g] = i < n;
+                uint64_t k = ~0ull;
+                if (valid[g]) k = nm_point_key(xyz + i * 3, L);
+                sb[g] = k >> NM_LOCAL_BITS;
+                local[g] = (uint32_t)k & ((1u << NM_LOCAL_BITS) - 1u);
+                uint64_t prev = __shfl_up(sb[g], 1);
+                if (lane == 0) prev = carry;
+                carry = __shfl(sb[g], 63);
+                head[g] = valid[g] && sb[g] != prev;
             }
-            slot[g] = sl;
-        }
-        // the slot of a point that is not a head is its run head's
-#pragma unroll
-        for (int g = 0; g < FUSED_GROUPS; ++g) {
-            const unsigned long long hm = __ballot(head[g]) & below;
-            const int src = hm ? 63 - __clzll((long long)hm) : 0;
-            uint32_t sl = __shfl(slot[g], src);
-            if (!hm) sl = carry_slot;
-            carry_slot = __shfl(sl, 63);
-            stash_slot[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane] = sl;
-            stash_local[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane] = (uint16_t)local[g];
-        }
-    }
-    __syncthreads();
-    // ---- the block's new leaves: one counter bump, zeroed, then published
-    const uint32_t total = won_count;
-    if (total) {
-        if (threadIdx.x == 0) leaf_base = atomicAdd(&I.counters[0], total);
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
-            const uint32_t idx = leaf_base + t;
-            if (idx < I.leaf_capacity) {
-                // device-scope stores: they go through to memory, where the other blocks' atomics
-                // on this leaf will execute (a plain store would sit in this XCD's L2 until a
-                // release fence writes the whole L2 back - measured: 8x slower kernel)
-                unsigned long long* leaf = (unsigned long long*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
-#pragma unroll
-                for (int q = 0; q < NM_LEAF_WORDS / 2; ++q)
-                    __hip_atomic_store(leaf + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                I.counters[2] = 1u;
-                I.status[NM_ST_LEAF_OVERFLOW] = 1u;
+    #pragma unroll
+            for (int g = 0; g < FUSED_GROUPS; ++g) {
+                slot[g] = nm_hash64(sb[g]) & I.hash_mask;
+                peek[g] = head[g] ? I.hash[slot[g]].key : sb[g];
             }
-        }
-        // the zeroes must have arrived before anyone can learn the leaf number
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
-            const uint32_t idx = leaf_base + t;
-            __hip_atomic_store(&I.hash[won_slot[t]].val, idx < I.leaf_capacity ? idx : LEAF_NONE,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    // ---- phase 2: the bits.  (the scratch now is the table of row words)
-    for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
-        t_word[t] = BITS_EMPTY;
-        t_bits[t] = 0u;
-    }
-    __syncthreads();
-    for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {
-        if (wave_lo + (int64_t)it * 64 >= n) break;
-        uint32_t sl[FUSED_GROUPS], loc[FUSED_GROUPS];
-        bool valid[FUSED_GROUPS], row_head[FUSED_GROUPS], sb_head[FUSED_GROUPS];
-        uint32_t val[FUSED_GROUPS];
-#pragma unroll
-        for (int g = 0; g < FUSED_GROUPS; ++g) {
-            sl[g] = stash_slot[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane];
-            loc[g] = stash_local[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane];
-            valid[g] = wave_lo + (int64_t)(it + g) * 64 + lane < n;
-            const uint32_t prev_sl = __shfl_up(sl[g], 1);
-            const uint32_t prev_loc = __shfl_up(loc[g], 1);
-            // runs are delimited inside one group of 64 only: lane 0 always starts one
-            sb_head[g] = lane == 0 || sl[g] != prev_sl || !valid[g];
-            row_head[g] = sb_head[g] || (loc[g] >> NM_SBX_BITS) != (prev_loc >> NM_SBX_BITS);
-            val[g] = LEAF_NONE;
-            if (sb_head[g] && valid[g])
-                val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int g = 0; g < FUSED_GROUPS; ++g) {
-            if (sb_head[g] && valid[g]) {
-                // not published yet: its creator is still in phase 1
-                for (int spin = 0; val[g] == LEAF_PENDING && spin < NM_SPIN_LIMIT; ++spin) {
-                    __builtin_amdgcn_s_sleep(8);
-                    val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                }
-#ifdef NM_DIAG_FORCE_TIMEOUT
-                // diagnostic build (tests only): the first block behaves as if its first wait ran out
-                if (blockIdx.x == 0 && it == 0 && g == 0) val[g] = LEAF_PENDING;
-#endif
-                if (val[g] == LEAF_PENDING) {
-                    I.counters[3] = 1u;
-                    I.status[NM_ST_INDEX_TIMEOUT] = 1u;     // sticky: the next call into the library fails
-                    val[g] = LEAF_NONE;
-                }
-            }
-            const unsigned long long sbm = __ballot(sb_head[g]);
-            const int32_t leaf = (int32_t)__shfl(val[g], 63 - __clzll((long long)(sbm & below)));
-            const unsigned long long rowm = __ballot(row_head[g]);
-            const int seg_start = 63 - __clzll((long long)(rowm & below));
-            uint32_t bits = valid[g] ? (1u << (loc[g] & 31u)) : 0u;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t other = __shfl_up(bits, off);
-                if (lane - off >= seg_start) bits |= other;
-            }
-            const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull));
-            if (tail && leaf >= 0) {
-                const uint32_t word = (uint32_t)leaf * NM_LEAF_WORDS + (loc[g] >> NM_SBX_BITS);
-                uint32_t ts = (word * 0x9E3779B1u) >> (32 - FUSED_TABLE_BITS);
-                bool stored = false;
-#pragma unroll 1
-                for (int probe = 0; probe < 8; ++probe) {
-                    const uint32_t seen = atomicCAS(&t_word[ts], BITS_EMPTY, word);
-                    if (seen == BITS_EMPTY || seen == word) {
-                        atomicOr(&t_bits[ts], bits);
-                        stored = true;
+    #pragma unroll
+            for (int g = 0; g < FUSED_GROUPS; ++g) {
+                if (!head[g] || peek[g] == sb[g]) continue;      // already in the table, at slot[g]
+                uint32_t sl = slot[g];
+                uint64_t pk = peek[g];
+                for (;;) {
+                    if (pk == sb[g]) break;
+                    if (pk != NM_HASH_EMPTY) {
+                        sl = (sl + 1) & I.hash_mask;
+                        pk = I.hash[sl].key;
+                        continue;
+                    }
+                    const unsigned long long seen =
+                        atomicCAS((unsigned long long*)&I.hash[sl].key,
+                                  (unsigned long long)NM_HASH_EMPTY, (unsigned long long)sb[g]);
+                    if (seen == NM_HASH_EMPTY) {
+                        won_slot[atomicAdd(&won_count, 1u)] = sl;
                         break;
                     }
-                    ts = (ts + 1) & (FUSED_TABLE - 1);
+                    if (seen == sb[g]) break;
+                    sl = (sl + 1) & I.hash_mask;
+                    pk = I.hash[sl].key;
                 }
-                if (!stored) atomicOr(&I.leaf[word], bits);
+                slot[g] = sl;
+            }
+            // the slot of a point that is not a head is its run head's
+    #pragma unroll
+            for (int g = 0; g < FUSED_GROUPS; ++g) {
+                const unsigned long long hm = __ballot(head[g]) & below;
+                const int src = hm ? 63 - __clzll((long long)hm) : 0;
+                uint32_t sl = __shfl(slot[g], src);
+                if (!hm) sl = carry_slot;
+                carry_slot = __shfl(sl, 63);
+                stash_slot[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane] = sl;
+                stash_local[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane] = (uint16_t)local[g];
             }
         }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
-        const uint32_t word = t_word[t];
-        if (word != BITS_EMPTY) atomicOr(&I.leaf[word], t_bits[t]);
+        __syncthreads();
+        // ---- the block's new leaves: one counter bump, zeroed, then published
+        const uint32_t total = won_count;
+        if (total) {
+            if (threadIdx.x == 0) leaf_base = atomicAdd(&I.counters[0], total);
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
+                const uint32_t idx = leaf_base + t;
+                if (idx < I.leaf_capacity) {
+                    // device-scope stores: they go through to memory, where the other blocks' atomics
+                    // on this leaf will execute (a plain store would sit in this XCD's L2 until a
+                    // release fence writes the whole L2 back - measured: 8x slower kernel)
+                    unsigned long long* leaf = (unsigned long long*)(I.leaf + (size_t)idx * NM_LEAF_WORDS);
+    #pragma unroll
+                    for (int q = 0; q < NM_LEAF_WORDS / 2; ++q)
+                        __hip_atomic_store(leaf + q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    I.counters[2] = 1u;
+                    I.status[NM_ST_LEAF_OVERFLOW] = 1u;
+                }
+            }
+            // the zeroes must have arrived before anyone can learn the leaf number
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
+                const uint32_t idx = leaf_base + t;
+                __hip_atomic_store(&I.hash[won_slot[t]].val, idx < I.leaf_capacity ? idx : LEAF_NONE,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: the bits.  (the scratch now is the table of row words)
+        for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
+            t_word[t] = BITS_EMPTY;
+            t_bits[t] = 0u;
+        }
+        __syncthreads();
+        for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {
+            if (wave_lo + (int64_t)it * 64 >= n) break;
+            uint32_t sl[FUSED_GROUPS], loc[FUSED_GROUPS];
+            bool valid[FUSED_GROUPS], row_head[FUSED_GROUPS], sb_head[FUSED_GROUPS];
+            uint32_t val[FUSED_GROUPS];
+    #pragma unroll
+            for (int g = 0; g < FUSED_GROUPS; ++g) {
+                sl[g] = stash_slot[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane];
+                loc[g] = stash_local[w * FUSED_WAVE_KEYS + (it + g) * 64 + lane];
+                valid[g] = wave_lo + (int64_t)(it + g) * 64 + lane < n;
+                const uint32_t prev_sl = __shfl_up(sl[g], 1);
+                const uint32_t prev_loc = __shfl_up(loc[g], 1);
+                // runs are delimited inside one group of 64 only: lane 0 always starts one
+                sb_head[g] = lane == 0 || sl[g] != prev_sl || !valid[g];
+                row_head[g] = sb_head[g] || (loc[g] >> NM_SBX_BITS) != (prev_loc >> NM_SBX_BITS);
+                val[g] = LEAF_NONE;
+                if (sb_head[g] && valid[g])
+                    val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+            }
+    #pragma unroll
+            for (int g = 0; g < FUSED_GROUPS; ++g) {
+                if (sb_head[g] && valid[g]) {
+                    // not published yet: its creator is still in phase 1
+                    for (int spin = 0; val[g] == LEAF_PENDING && spin < NM_SPIN_LIMIT; ++spin) {
+                        __builtin_amdgcn_s_sleep(8);
+                        val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    }
+    #ifdef NM_DIAG_FORCE_TIMEOUT
+                    // diagnostic build (tests only): the first block behaves as if its first wait ran out
+                    if (blockIdx.x == 0 && it == 0 && g == 0) val[g] = LEAF_PENDING;
+    #endif
+                    if (val[g] == LEAF_PENDING) {
+                        I.counters[3] = 1u;
+                        I.status[NM_ST_INDEX_TIMEOUT] = 1u;     // sticky: the next call into the library fails
+                        val[g] = LEAF_NONE;
+                    }
+                }
+                const unsigned long long sbm = __ballot(sb_head[g]);
+                const int32_t leaf = (int32_t)__shfl(val[g], 63 - __clzll((long long)(sbm & below)));
+                const unsigned long long rowm = __ballot(row_head[g]);
+                const int seg_start = 63 - __clzll((long long)(rowm & below));
+                uint32_t bits = valid[g] ? (1u << (loc[g] & 31u)) : 0u;
+    #pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t other = __shfl_up(bits, off);
+                    if (lane - off >= seg_start) bits |= other;
+                }
+                const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull));
+                if (tail && leaf >= 0) {
+                    const uint32_t word = (uint32_t)leaf * NM_LEAF_WORDS + (loc[g] >> NM_SBX_BITS);
+                    uint32_t ts = (word * 0x9E3779B1u) >> (32 - FUSED_TABLE_BITS);
+                    bool stored = false;
+    #pragma unroll 1
+                    for (int probe = 0; probe < 8; ++probe) {
+                        const uint32_t seen = atomicCAS(&t_word[ts], BITS_EMPTY, word);
+                        if (seen == BITS_EMPTY || seen == word) {
+                            atomicOr(&t_bits[ts], bits);
+                            stored = true;
+                            break;
+                        }
+                        ts = (ts + 1) & (FUSED_TABLE - 1);
+                    }
+                    if (!stored) atomicOr(&I.leaf[word], bits);
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
+            const uint32_t word = t_word[t];
+            if (word != BITS_EMPTY) atomicOr(&I.leaf[word], t_bits[t]);
+        }
     }
 }
 
@@ -851,102 +862,293 @@ __device__ __forceinline__ uint64_t nm_spread2(uint32_t v)
     return x;
 }
 
-// how the three axes share the compact Z-order key (see k_order_keys)
-struct ZLayout {
-    int32_t w1, w2;        // smallest and middle width (after NM_ORDER_DROP)
-    int32_t off2[3];       // slot of an axis in the 2-way zone, -1 for the axis with the smallest width
-};
+// (measured in round 1: dropping 2 key bits per axis saves a radix pass but costs more in the index build and
+// the search kernel)
 
-constexpr int NM_ORDER_DROP = 0;   // measured: dropping 2 bits per axis saves a radix pass but costs more in the index build and the fused kernel
-
-template <typename KeyT>
 __global__ __launch_bounds__(256) void k_order_keys(const double* __restrict__ xyz, int64_t n,
-                                                    int64_t stride, LatticeDev L, int morton,
-                                                    ZLayout Z, KeyT* __restrict__ key,
+                                                    int64_t stride,
+                                                    const OrderDev* __restrict__ order_dev,
+                                                    uint32_t* __restrict__ key,
                                                     uint32_t* __restrict__ val)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double* p = xyz + i * stride;
-    int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
-    int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
-    int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
-    cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
-    cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
-    cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
-    // the order only has to be spatially coherent: blocks of 4x4x4 finest cells are left unordered
-    // inside, which takes 6 bits (one radix pass at this size) off the sort
-    uint64_t k;
-    if (morton) {
-        // Z-order with the always-zero bits squeezed out: bit b of every axis that HAS a bit b, lowest
-        // bits first - same order as the plain 3-way interleave, but only wx+wy+wz key bits to sort.
-        // with w1 <= w2 the two smaller widths: bits below w1 are interleaved 3-way, bits in [w1, w2)
-        // 2-way among the axes that still have bits, the rest belongs to the widest axis alone.
-        const uint32_t c[3] = {(uint32_t)cx >> NM_ORDER_DROP, (uint32_t)cy >> NM_ORDER_DROP,
-                               (uint32_t)cz >> NM_ORDER_DROP};
-        k = 0ull;
+    const OrderDev& O = *order_dev;
+    uint64_t k = 0ull;
+    if (O.valid) {
+        const LatticeDev& L = O.L;
+        const ZLayout& Z = O.Z;
+        const double* p = xyz + i * stride;
+        int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
+        int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
+        int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
+        cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
+        cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
+        cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
+        if (O.morton) {
+            // Z-order with the always-zero bits squeezed out: bit b of every axis that HAS a bit b, lowest
+            // bits first - same order as the plain 3-way interleave, but only wx+wy+wz key bits to sort.
+            // with w1 <= w2 the two smaller widths: bits below w1 are interleaved 3-way, bits in [w1, w2)
+            // 2-way among the axes that still have bits, the rest belongs to the widest axis alone.
+            const uint32_t c[3] = {(uint32_t)cx, (uint32_t)cy, (uint32_t)cz};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const uint32_t lo = c[a] & ((1u << Z.w1) - 1u);
-            k |= nm_spread3(lo) << a;
-            if (Z.off2[a] >= 0) {
-                const uint32_t mid = (c[a] >> Z.w1) & ((1u << (Z.w2 - Z.w1)) - 1u);
-                k |= nm_spread2(mid) << (3 * Z.w1 + Z.off2[a]);
-                k |= (uint64_t)(c[a] >> Z.w2) << (3 * Z.w1 + 2 * (Z.w2 - Z.w1));
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t lo = c[a] & ((1u << Z.w1) - 1u);
+                k |= nm_spread3(lo) << a;
+                if (Z.off2[a] >= 0) {
+                    const uint32_t mid = (c[a] >> Z.w1) & ((1u << (Z.w2 - Z.w1)) - 1u);
+                    k |= nm_spread2(mid) << (3 * Z.w1 + Z.off2[a]);
+                    k |= (uint64_t)(c[a] >> Z.w2) << (3 * Z.w1 + 2 * (Z.w2 - Z.w1));
+                }
             }
+        } else {
+            k = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
         }
-    } else {
-        k = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
+        // the order only has to be spatially coherent: a key wider than 32 bits loses its low bits (the
+        // points of a small block of finest cells then stay in input order)
+        k >>= O.shift;
     }
-    key[i] = (KeyT)k;
+    key[i] = (uint32_t)k;
     val[i] = (uint32_t)i;
 }
 
-int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const LatticeDev& L,
-                   uint64_t* key_tmp, uint32_t* val_tmp, uint64_t* key_sorted, uint32_t* order,
-                   void* sort_temp, size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s)
+// the spatial order of a lattice: which key, how its bits are laid out, what is dropped to fit 32 bits
+__host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O)
 {
+    O->L = L;
     int wmax = L.wx > L.wy ? L.wx : L.wy;
     if (L.wz > wmax) wmax = L.wz;
-    const int morton = wmax <= 21;
-    int sort_bits = 0;
-    for (int w : {L.wx, L.wy, L.wz}) sort_bits += w > NM_ORDER_DROP ? w - NM_ORDER_DROP : 0;
-    if (sort_bits < 1) sort_bits = 1;
-    const unsigned bits = morton ? (unsigned)sort_bits : (unsigned)L.keybits;
+    O->morton = wmax <= 21;
     // axis roles in the compact Z-order key: the axis with the smallest width drops out of the 2-way
     // zone; with ties the later axis is treated as the smaller one (it then simply has no bits there)
-    int wd[3] = {L.wx - NM_ORDER_DROP, L.wy - NM_ORDER_DROP, L.wz - NM_ORDER_DROP};
-    for (int a = 0; a < 3; ++a) wd[a] = wd[a] > 0 ? wd[a] : 0;
+    const int wd[3] = {L.wx, L.wy, L.wz};
     int smallest = 0;
     for (int a = 1; a < 3; ++a)
         if (wd[a] <= wd[smallest]) smallest = a;
-    ZLayout Z;
-    Z.w1 = wd[smallest];
-    Z.w2 = 64;
+    O->Z.w1 = wd[smallest];
+    O->Z.w2 = 64;
     for (int a = 0, slot2 = 0; a < 3; ++a) {
         if (a == smallest) {
-            Z.off2[a] = -1;
+            O->Z.off2[a] = -1;
         } else {
-            Z.off2[a] = slot2++;
-            if (wd[a] < Z.w2) Z.w2 = wd[a];
+            O->Z.off2[a] = slot2++;
+            if (wd[a] < O->Z.w2) O->Z.w2 = wd[a];
         }
     }
-    if (bits <= 32) {
-        // the compact key usually fits 32 bits (31 at 10 M points of the benchmark scene): the sort
-        // then moves 8 instead of 12 bytes per pair and pass
-        uint32_t* k32 = (uint32_t*)key_tmp;
-        uint32_t* k32_sorted = (uint32_t*)key_sorted;
-        k_order_keys<uint32_t><<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, morton, Z,
-                                                                     k32, val_tmp);
-        NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, k32, k32_sorted, val_tmp,
-                                              order, (size_t)n, 0, bits, s));
-    } else {
-        k_order_keys<uint64_t><<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, morton, Z,
-                                                                     key_tmp, val_tmp);
-        NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp,
-                                              order, (size_t)n, 0, bits, s));
-    }
+    const int bits = O->morton ? L.wx + L.wy + L.wz : L.keybits;
+    O->shift = bits > 32 ? bits - 32 : 0;
+    O->valid = 1;
+}
+
+int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                   const OrderDev* d_order_dev, unsigned sort_bits, uint32_t* key_tmp,
+                   uint32_t* val_tmp, uint32_t* key_sorted, uint32_t* order, void* sort_temp,
+                   size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s)
+{
+    if (sort_bits < 1) sort_bits = 1;
+    if (sort_bits > 32) sort_bits = 32;
+    // the compact key always fits 32 bits (31 at 10 M points of the benchmark scene): the sort moves 8
+    // bytes per pair and pass
+    k_order_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, d_order_dev, key_tmp, val_tmp);
+    NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp, order,
+                                          (size_t)n, 0, sort_bits, s));
     k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+// ---- the ladder in device memory ------------------------------------------------------------------------
+// scalar lattice parameters of VoxelFilter.__init__ / _calculate_shift (geometry.py:37-64) on the device:
+//   min_corner = min - e/2, max_corner = max + e/2                       geometry.py:37-38
+//   widths = ceil(log2((max_corner - min_corner) / e))                   geometry.py:56
+// numpy's log2 is an fp64 function: ceil(fl(log2 x)).  for x = 2^k (1 + f) that is k + 1 unless the sum
+// k + f/ln 2 rounds back to k in fp64 - only for f below 2^-40 or so - which is reproduced here from the
+// exponent and the mantissa of x, without a log2 in device code.
+__device__ inline int32_t nm_ceil_log2(double x)
+{
+    if (!(x > 0.0) || isinf(x)) return -10000;
+    int ex = 0;
+    const double m = frexp(x, &ex);          // x = m * 2^ex, m in [0.5, 1)
+    const int k = ex - 1;                    // x = (2m) * 2^k, 2m in [1, 2)
+    const double f = 2.0 * m - 1.0;          // exact
+    if (f == 0.0) return k;
+    if (f < 0x1p-30) {
+        const double l = (double)k + f * 1.4426950408889634;     // fl(log2 x) to first order in f
+        return (int32_t)ceil(l);
+    }
+    return k + 1;
+}
+
+struct LadderSpec {
+    int32_t n_scales;
+    int32_t finest;                    // scale whose lattice orders the cloud
+    double edge[NM_MAX_LADDER];
+    double radius[NM_MAX_LADDER];
+    // where each scale's index lives (host-computed from the point count alone)
+    HashEntry* hash[NM_MAX_LADDER];
+    uint32_t* leaf[NM_MAX_LADDER];
+    uint32_t* counters[NM_MAX_LADDER];
+    uint32_t hash_capacity;            // slots allocated per scale (power of two)
+    uint32_t leaf_capacity;            // leaves allocated per scale
+};
+
+__device__ inline void nm_scale_finish(ScaleDev* S, double radius, uint32_t hash_capacity,
+                                       uint32_t leaf_capacity)
+{
+    const LatticeDev& L = S->L;
+    // as many leaves as the lattice has superblocks or the cloud has points, whichever is smaller; the
+    // table is kept at most half full
+    uint64_t cap = 1ull << (L.bx + L.by + L.bz);
+    if (cap > leaf_capacity) cap = leaf_capacity;
+    if (cap < 1) cap = 1;
+    uint64_t hcap = 64;
+    while (hcap < cap * 2 && hcap < hash_capacity) hcap <<= 1;
+    S->I.hash_mask = (uint32_t)(hcap - 1);
+    S->I.leaf_capacity = (uint32_t)cap;
+    S->r2 = radius * radius;
+    // static pruning of the candidate window is sound only while the rounding of cells and centres stays
+    // far below the 1e-4-cell padding of the bounds: 16 ulp of the largest coordinate the lattice can
+    // produce must be smaller than that
+    double maxabs = 0.0;
+    const double mins[3] = {L.min_x, L.min_y, L.min_z};
+    const int32_t ws[3] = {L.wx, L.wy, L.wz};
+    for (int a = 0; a < 3; ++a) {
+        const double lo = mins[a];
+        const double hi = lo + ldexp(L.edge, ws[a]);
+        maxabs = fmax(maxabs, fmax(fabs(lo), fabs(hi)));
+    }
+    S->prune_ok = 16.0 * maxabs * 2.220446049250313e-16 < 1e-4 * L.edge ? 1 : 0;
+}
+
+// from the cloud's extrema (6 doubles on the device) to every scale's lattice.  one thread per scale.
+__global__ void k_make_ladder(const double* __restrict__ minmax, LadderSpec P, ScaleDev* __restrict__ ladder,
+                              OrderDev* __restrict__ order_dev, uint32_t* __restrict__ status)
+{
+    const int sc = threadIdx.x;
+    if (sc < P.n_scales) {
+        ScaleDev S;
+        const double e = P.edge[sc];
+        const double half = e / 2;
+        int32_t w[3];
+        double mn[3];
+        int32_t bad = 0;
+        int sum = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double lo = minmax[a], hi = minmax[3 + a];
+            if (!(lo <= hi) || isinf(lo) || isinf(hi)) bad = NM_LAT_NOT_FINITE;
+            mn[a] = lo - half;
+            const double mx = hi + half;
+            w[a] = nm_ceil_log2((mx - mn[a]) / e);
+            sum += w[a];
+        }
+        if (!bad) {
+            if (sum > 64) bad = NM_LAT_TOO_SMALL_EDGE;                       // geometry.py:59-60
+            else if (w[0] < 1 || w[1] < 1 || w[2] < 1) bad = NM_LAT_NO_EXTENT;
+            else if (w[0] > 30 || w[1] > 30 || w[2] > 30) bad = NM_LAT_DEVICE_LIMIT;
+        }
+        if (bad) {
+            for (int a = 0; a < 3; ++a) w[a] = 1;                            // harmless placeholders
+            status[NM_ST_LATTICE] = (uint32_t)bad;
+        }
+        LatticeDev& L = S.L;
+        L.min_x = mn[0]; L.min_y = mn[1]; L.min_z = mn[2];
+        L.edge = e;
+        L.half_edge = e * 0.5;
+        L.wx = w[0]; L.wy = w[1]; L.wz = w[2];
+        L.s0 = w[0];
+        L.s1 = w[0] + w[1];
+        L.bx = L.wx > NM_SBX_BITS ? L.wx - NM_SBX_BITS : 0;
+        L.by = L.wy > NM_SBY_BITS ? L.wy - NM_SBY_BITS : 0;
+        L.bz = L.wz > NM_SBZ_BITS ? L.wz - NM_SBZ_BITS : 0;
+        L.keybits = NM_LOCAL_BITS + L.bx + L.by + L.bz;
+        S.I.hash = P.hash[sc];
+        S.I.leaf = P.leaf[sc];
+        S.I.counters = P.counters[sc];
+        S.I.status = status;
+        S.valid = bad ? 0 : 1;
+        nm_scale_finish(&S, P.radius[sc], P.hash_capacity, P.leaf_capacity);
+        ladder[sc] = S;
+        if (sc == P.finest) {
+            OrderDev O;
+            nm_order_plan(S.L, &O);
+            O.valid = S.valid;
+            *order_dev = O;
+        }
+    }
+}
+
+// the same array from lattices the host already has (nm_multiscale_features, nm_scale_features)
+struct LadderPut {
+    int32_t n_scales;
+    int32_t first;                     // index of P.scale[0] in the device array
+    int32_t finest;                    // index (in the device array) of the ordering scale, -1: not here
+    ScaleDev scale[8];
+    double radius[8];
+    uint32_t hash_capacity[8], leaf_capacity[8];
+};
+
+__global__ void k_put_ladder(LadderPut P, ScaleDev* __restrict__ ladder, OrderDev* __restrict__ order_dev)
+{
+    const int t = threadIdx.x;
+    if (t < P.n_scales) {
+        ScaleDev S = P.scale[t];
+        S.valid = 1;
+        const uint32_t hmask = S.I.hash_mask, lcap = S.I.leaf_capacity;
+        nm_scale_finish(&S, P.radius[t], P.hash_capacity[t], P.leaf_capacity[t]);
+        // the host sized this index exactly: keep its numbers
+        S.I.hash_mask = hmask;
+        S.I.leaf_capacity = lcap;
+        ladder[P.first + t] = S;
+        if (order_dev && P.first + t == P.finest) {
+            OrderDev O;
+            nm_order_plan(S.L, &O);
+            *order_dev = O;
+        }
+    }
+}
+
+int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const double* radii, int n_scales,
+                  int finest, ScaleDev* d_ladder, OrderDev* d_order, hipStream_t s)
+{
+    for (int first = 0; first < n_scales; first += 8) {
+        LadderPut P;
+        P.n_scales = n_scales - first < 8 ? n_scales - first : 8;
+        P.first = first;
+        P.finest = finest;
+        for (int t = 0; t < P.n_scales; ++t) {
+            P.scale[t].L = L[first + t];
+            P.scale[t].I = I[first + t];
+            P.scale[t].r2 = 0.0;
+            P.scale[t].valid = 1;
+            P.scale[t].prune_ok = 0;
+            P.radius[t] = radii[first + t];
+            P.hash_capacity[t] = I[first + t].hash_mask + 1u;
+            P.leaf_capacity[t] = I[first + t].leaf_capacity;
+        }
+        k_put_ladder<<<1, 64, 0, s>>>(P, d_ladder, d_order);
+    }
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const double* edges, const double* radii,
+                   int n_scales, int finest, void* const* hash, void* const* leaf, void* const* counters,
+                   uint32_t hash_capacity, uint32_t leaf_capacity, ScaleDev* d_ladder, OrderDev* d_order,
+                   hipStream_t s)
+{
+    LadderSpec P;
+    P.n_scales = n_scales;
+    P.finest = finest;
+    for (int i = 0; i < n_scales; ++i) {
+        P.edge[i] = edges[i];
+        P.radius[i] = radii[i];
+        P.hash[i] = (HashEntry*)hash[i];
+        P.leaf[i] = (uint32_t*)leaf[i];
+        P.counters[i] = (uint32_t*)counters[i];
+    }
+    P.hash_capacity = hash_capacity;
+    P.leaf_capacity = leaf_capacity;
+    k_make_ladder<<<1, 64, 0, s>>>(d_minmax, P, d_ladder, d_order, ctx->d_status);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }
@@ -967,15 +1169,11 @@ IndexDev nm_index_at(nm_ctx* ctx, void* index_mem, const IndexLayout& lay)
 // the ladder keeps one index per scale and prepares / finishes them together: a launch that clears a few
 // megabytes or counts a few thousand leaves costs 5-8 us of which almost nothing is work, and there were
 // four of them per scale.
-struct IndexList {
-    int32_t n;
-    IndexDev I[NM_MAX_LADDER];
-};
 
 // hash tables to all ones (free), counter blocks to zero
-__global__ __launch_bounds__(256) void k_index_clear_all(IndexList Lst)
+__global__ __launch_bounds__(256) void k_index_clear_all(const ScaleDev* __restrict__ ladder)
 {
-    const IndexDev& I = Lst.I[blockIdx.y];
+    const IndexDev I = ladder[blockIdx.y].I;
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint4* h = (uint4*)I.hash;
@@ -986,10 +1184,10 @@ __global__ __launch_bounds__(256) void k_index_clear_all(IndexList Lst)
 }
 
 // M of every index (set bits of its allocated leaves)
-__global__ __launch_bounds__(256) void k_count_voxels_all(IndexList Lst)
+__global__ __launch_bounds__(256) void k_count_voxels_all(const ScaleDev* __restrict__ ladder)
 {
     __shared__ uint32_t wsum[4];
-    const IndexDev& I = Lst.I[blockIdx.y];
+    const IndexDev I = ladder[blockIdx.y].I;
     const uint32_t n_leaves = min(I.counters[0], I.leaf_capacity);
     const uint64_t words = (uint64_t)n_leaves * NM_LEAF_WORDS / 4;     // as uint4
     uint32_t c = 0;
@@ -1008,32 +1206,26 @@ __global__ __launch_bounds__(256) void k_count_voxels_all(IndexList Lst)
     }
 }
 
-int nm_index_clear_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s)
+int nm_index_clear_all(nm_ctx* ctx, const ScaleDev* d_ladder, int n, hipStream_t s)
 {
-    IndexList L;
-    L.n = n;
-    for (int i = 0; i < n; ++i) L.I[i] = list[i];
-    k_index_clear_all<<<dim3(256, n), 256, 0, s>>>(L);
+    k_index_clear_all<<<dim3(256, n), 256, 0, s>>>(d_ladder);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }
 
-int nm_index_count_all(nm_ctx* ctx, const IndexDev* list, int n, hipStream_t s)
+int nm_index_count_all(nm_ctx* ctx, const ScaleDev* d_ladder, int n, hipStream_t s)
 {
-    IndexList L;
-    L.n = n;
-    for (int i = 0; i < n; ++i) L.I[i] = list[i];
-    k_count_voxels_all<<<dim3(128, n), 256, 0, s>>>(L);
+    k_count_voxels_all<<<dim3(128, n), 256, 0, s>>>(d_ladder);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }
 
-// fills an index that nm_index_clear_all has prepared; its voxel count comes from nm_index_count_all
-int nm_index_build_any(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const LatticeDev& L,
-                       const IndexDev& I, hipStream_t s)
+// fills the indexes of scales [first, first + count) of a ladder that nm_index_clear_all has prepared
+int nm_index_build_ladder(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const ScaleDev* d_ladder,
+                          int first, int count, hipStream_t s)
 {
-    nm_profile_mark(ctx, s);      // end of the "keys" stage (order build), start of the "index" stage
-    k_index_fused<<<(int)((n + FUSED_CHUNK - 1) / FUSED_CHUNK), 256, 0, s>>>(sorted_xyz, n, L, I);
+    k_index_fused<<<(int)((n + FUSED_CHUNK - 1) / FUSED_CHUNK), 256, 0, s>>>(sorted_xyz, n,
+                                                                              d_ladder + first, count);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }

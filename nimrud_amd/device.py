@@ -37,7 +37,15 @@ class Runtime(object):
         """raise what a kernel of an earlier call reported (nm_check): an occupancy index that timed out
         or overflowed, a lattice built on the device that cannot be addressed.  wait=True waits for the
         status snapshot of the last call - callers that have just synchronised pay nothing."""
-        self.check(self.lib.nm_check(self.ctx, 1 if wait else 0))
+        rc = self.lib.nm_check(self.ctx, 1 if wait else 0)
+        if rc == _ffi.NM_ERR_LATTICE:
+            # what VoxelFilter.__init__ would have raised on the host (geometry.py:59-60): a property of
+            # that call's arguments, not of the context - report it once and carry on
+            msg = self.lib.nm_last_error(self.ctx)
+            msg = msg.decode("utf-8", "replace") if msg else "lattice cannot be addressed"
+            self.lib.nm_clear_error(self.ctx)
+            raise ValueError(msg)
+        self.check(rc)
 
     def clear_error(self):
         self.check(self.lib.nm_clear_error(self.ctx))

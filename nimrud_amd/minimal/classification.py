@@ -52,6 +52,8 @@ class ForestModel(object):
         self.packed = torch.from_numpy(packed.view(np.uint8)).to(dev)
         self.leaf_value = torch.from_numpy(leaf_value).to(dev)
         self.packed_roots = torch.from_numpy(packed_roots).to(dev)
+        packed8 = self.pack_nodes8(packed, self.n_features)
+        self.packed8 = torch.from_numpy(packed8.view(np.uint8)).to(dev) if packed8 is not None else None
         self._c = _ffi.NmForest(
             d_left=self.left.data_ptr(), d_right=self.right.data_ptr(),
             d_feature=self.feature.data_ptr(), d_threshold=self.threshold.data_ptr(),
@@ -60,7 +62,7 @@ class ForestModel(object):
             n_classes=self.value.shape[1], n_features=self.n_features,
             d_packed=self.packed.data_ptr(), d_leaf_value=self.leaf_value.data_ptr(),
             d_packed_roots=self.packed_roots.data_ptr(), n_leaves=self.leaf_value.shape[0],
-            reserved=0)
+            reserved=0, d_packed8=self.packed8.data_ptr() if self.packed8 is not None else None)
 
     @staticmethod
     def pack_nodes(left, right, feature, threshold, value, roots):
@@ -88,6 +90,30 @@ class ForestModel(object):
                     queue.append((int(right[old]), nxt + 1))
                     nxt += 2
         return rec, np.ascontiguousarray(np.stack(leaf_rows)), new_roots
+
+    @staticmethod
+    def pack_nodes8(rec, n_features):
+        """the renumbered nodes of pack_nodes as 8-byte records {fp32 threshold, uint32 packed} (struct
+        nm_forest::d_packed8).  sklearn sends a row left when (double)(float)x <= threshold; for an fp32
+        x that is the same as x <= the largest fp32 not above the threshold, so the threshold is stored
+        rounded DOWN to fp32 and the comparison done in fp32: bit-identical decisions, half the bytes per
+        node visit.  packed: bit 31 = leaf, then the leaf's row; else left child << 5 | feature.
+        None when the forest does not fit the fields (more than 32 features or 2^26 nodes)."""
+        if n_features > 32 or len(rec) >= (1 << 26):
+            return None
+        thr = rec["threshold"].astype(np.float64)
+        t32 = thr.astype(np.float32)
+        above = t32.astype(np.float64) > thr
+        t32[above] = np.nextafter(t32[above], np.float32(-np.inf))
+        assert np.all(t32.astype(np.float64) <= thr)
+        leaf = rec["left"] < 0
+        packed = np.where(leaf, np.uint32(1 << 31) | rec["feature"].astype(np.uint32),
+                          (rec["left"].astype(np.uint32) << np.uint32(5)) |
+                          rec["feature"].astype(np.uint32)).astype(np.uint32)
+        out = np.zeros(len(rec), dtype=np.dtype([("threshold", "<f4"), ("packed", "<u4")]))
+        out["threshold"] = t32
+        out["packed"] = packed
+        return out
 
     @staticmethod
     def flatten_sklearn(clf):
@@ -202,10 +228,36 @@ def confusion_matrix(predicted, truth, n_classes=None):
     return np.bincount(p * n + t, minlength=n * n).reshape(n, n).astype(np.float64)
 
 
-def classify_cloud(cloud, edge_lengths, radii, model, **kwargs):
-    """features + forest in one go for a cloud resident on the GPU (BASELINE config 5): returns
-    (labels int32 GPU tensor of class positions, (N, 4*S) feature tensor)."""
+FUSED_MAX_FEATURES, FUSED_MAX_CLASSES = 20, 8       # limits of nm_set_forest_output
+
+
+def classify_cloud(cloud, edge_lengths, radii, model, fused=True, want_proba=False, out=None, **kwargs):
+    """features + forest in one go for a cloud resident on the GPU (BASELINE config 5: "random-forest
+    classifier evaluation fused after feature assembly"): returns (labels int32 GPU tensor of class
+    positions, (N, 4*S) feature tensor) - and the (N, C) probabilities in between when want_proba.
+    fused=True evaluates the forest inside the search kernel, right behind each row's last scale
+    (nm_set_forest_output): the wave that has just finished a row reads it back out of L2 and its 64
+    spatially neighbouring lanes walk the trees together.  forests outside the fused path's limits (more
+    than 20 features or 8 classes) and fused=False evaluate the finished matrix with nm_forest_eval; the
+    numbers are the same."""
     from nimrud_amd.minimal import multiscale
-    feats = multiscale.process_gpu(cloud, cloud, edge_lengths, radii, **kwargs)
-    _, label, _ = model._eval(feats, False, True)
-    return label, feats
+    n_features = 4 * len(edge_lengths)
+    can_fuse = (fused and model.packed8 is not None and model.n_features == n_features and
+                n_features <= FUSED_MAX_FEATURES and model._c.n_classes <= FUSED_MAX_CLASSES and
+                not kwargs.get("verbose") and not kwargs.get("per_scale"))
+    if not can_fuse:
+        feats = multiscale.process_gpu(cloud, cloud, edge_lengths, radii, out=out, **kwargs)
+        proba, label, _ = model._eval(feats, want_proba, True)
+        return (label, proba, feats) if want_proba else (label, feats)
+    rt, dev_cloud = _device.as_cloud(cloud)
+    n = dev_cloud.shape[0]
+    label = torch.empty(n, dtype=torch.int32, device=rt.device)
+    proba = torch.empty((n, model._c.n_classes), dtype=torch.float64, device=rt.device) \
+        if want_proba else None
+    rt.check(rt.lib.nm_set_forest_output(rt.ctx, ctypes.byref(model._c), _device.ptr(proba),
+                                         model._c.n_classes, _device.ptr(label)))
+    try:
+        feats = multiscale.process_gpu(dev_cloud, dev_cloud, edge_lengths, radii, out=out, **kwargs)
+    finally:
+        rt.check(rt.lib.nm_set_forest_output(rt.ctx, None, None, 0, None))
+    return (label, proba, feats) if want_proba else (label, feats)

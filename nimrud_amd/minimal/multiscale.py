@@ -20,7 +20,6 @@ occupancy index -> fused search/moments/eigen kernel.  see DESIGN.md.
 """
 
 import ctypes
-import functools
 import time
 
 import numpy as np
@@ -64,49 +63,32 @@ def _scale_into(rt, query, search, shared, lo, hi, edge_length, radius, out_view
         _device.ptr(work), work.numel(), rt.stream()))
 
 
-@functools.lru_cache(maxsize=32)
-def _ladder_lattices(lo, hi, edge_lengths):
-    """the nm_lattice array of a ladder over a cloud with extrema lo, hi (VoxelFilter.__init__,
-    geometry.py:37-64, per scale).  a pure function of three tuples of floats, and a dozen small numpy
-    calls per scale: remembered, because a pipeline calls the ladder on the same cloud again and again
-    (the extrema themselves are still measured on the device at every call)."""
-    from nimrud_amd import _ffi
-    lats = (_ffi.NmLattice * len(edge_lengths))()
-    for s, e in enumerate(edge_lengths):
-        min_corner, _, widths, _ = geometry.lattice_parameters(np.asarray(lo), np.asarray(hi), e)
-        if np.any(widths < 1):
-            # the reference fails here too: int("0b" + "1"*0, 2) at geometry.py:74
-            raise ValueError("cloud has no extent beyond one voxel on some axis")
-        lat = geometry.make_nm_lattice(min_corner, e, widths)
-        ctypes.memmove(ctypes.byref(lats[s]), ctypes.byref(lat), ctypes.sizeof(_ffi.NmLattice))
-    return lats
-
-
 def _ladder_into(rt, query, search, shared, bounds, edge_lengths, radii, out, info, knn_min=0,
                  knn_radius_factor=3.0):
-    """enqueue the whole ladder in one library call (nm_multiscale_features): the cloud is sorted
-    once, every scale's index is built from that order.  bounds: the search cloud's extrema, (lo, hi)
-    host arrays or a (6,) device tensor."""
-    from nimrud_amd import _ffi
-    if isinstance(bounds, torch.Tensor):
-        mm = bounds.cpu().numpy()
-        lo, hi = mm[:3], mm[3:]
-    else:
-        lo, hi = bounds
+    """enqueue the whole ladder in one library call (nm_ladder_features): the cloud is sorted once, every
+    scale's lattice is built on the device from the search cloud's extrema and every index from that
+    order.  nothing visits the host: the call can be queued behind other work.
+    bounds: None (the library measures the search cloud) or a (6,) fp64 device tensor {min xyz, max xyz}
+    - the global extrema of a multi-GPU job."""
     # the fallback switch is context state in the C ABI: always set it, so no call inherits another's
     rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
     n_scales = len(edge_lengths)
-    lats = _ladder_lattices(tuple(float(v) for v in lo), tuple(float(v) for v in hi),
-                            tuple(float(e) for e in edge_lengths))
+    edg = (ctypes.c_double * n_scales)(*[float(e) for e in edge_lengths])
     rad = (ctypes.c_double * n_scales)(*[float(r) for r in radii])
     nq, ns = query.shape[0], search.shape[0]
-    nbytes = rt.lib.nm_multiscale_workspace_bytes(nq, ns, lats, n_scales)
+    nbytes = rt.lib.nm_ladder_workspace_bytes(nq, ns, n_scales)
+    if nbytes == 0:
+        raise ValueError("bad ladder arguments (at most 32 scales per call)")
     work = rt.workspace(nbytes)
     qt = search if shared else query
-    rt.check(rt.lib.nm_multiscale_features(
+    if bounds is not None and not (isinstance(bounds, torch.Tensor) and bounds.is_cuda and
+                                   bounds.dtype == torch.float64 and bounds.numel() == 6
+                                   and bounds.is_contiguous()):
+        raise ValueError("bounds must be a contiguous (6,) fp64 tensor on the device")
+    rt.check(rt.lib.nm_ladder_features(
         rt.ctx, _device.ptr(qt), nq, _device.row_stride(qt),
-        _device.ptr(search), ns, _device.row_stride(search), lats, rad, n_scales,
-        _device.ptr(out), int(out.stride(0)), _device.ptr(info),
+        _device.ptr(search), ns, _device.row_stride(search), edg, rad, n_scales,
+        _device.ptr(bounds), _device.ptr(out), int(out.stride(0)), _device.ptr(info),
         _device.ptr(work), work.numel(), rt.stream()))
 
 
@@ -127,8 +109,11 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
                 return_info=False, out=None, per_scale=False, knn_min=0, knn_radius_factor=3.0,
                 cov_out=None, normal_out=None):
     """process_single_core for clouds resident in HBM: torch GPU tensors in, (Nq, 4*S) fp64 GPU tensor
-    out.  nothing crosses PCIe except six doubles (the search cloud's extrema) and, when strict or
-    return_info, 4 counters per scale.
+    out.  nothing crosses PCIe, and nothing waits for the device: the lattices are built on the GPU from
+    the cloud's extrema (nm_ladder_features), so the call only enqueues work.  what the reference's
+    VoxelFilter raises synchronously for an unusable edge length (geometry.py:59-60) therefore surfaces
+    at the next synchronisation point: strict / return_info (which read 4 counters per scale back),
+    process_single_core, the next call into the library, or `nimrud_amd.device.get_runtime().check_async()`.
     the ladder normally runs as ONE library call that sorts the cloud once for all scales;
     verbose=True or per_scale=True runs one self-contained call per scale instead (same numbers).
     knn_min > 0 switches on the k-nearest-voxel fallback (an extension the reference does not have,
@@ -174,8 +159,10 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
                 and normal_out.shape[1] >= 3 * n_scales and normal_out.stride(1) == 1):
             raise ValueError("normal_out must be a (Nq, >= 3*S) fp64 tensor on the clouds' device")
     outer_start = time.perf_counter()
-    lo, hi = _device.cloud_bounds(rt, search)
     rt.check(rt.lib.nm_set_knn_fallback(rt.ctx, int(knn_min), float(knn_radius_factor)))
+    lo = hi = None
+    if verbose or per_scale:
+        lo, hi = _device.cloud_bounds(rt, search)       # the per-scale form builds its lattices here
 
     def covariance_columns(first_scale):
         # context state of the C ABI, like the fallback switch: set for this call, cleared after it
@@ -190,7 +177,7 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
     try:
         if not (verbose or per_scale):
             covariance_columns(0)
-            _ladder_into(rt, query, search, shared, (lo, hi), edge_lengths, radii, out, info,
+            _ladder_into(rt, query, search, shared, None, edge_lengths, radii, out, info,
                          knn_min=knn_min, knn_radius_factor=knn_radius_factor)
             edge_lengths_loop = []
         else:
@@ -214,12 +201,7 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
 
     if strict or return_info:
         host = info.cpu().numpy()
-        if (host[:n_scales, 0] < 0).any():
-            # the index builder's bounded wait for a leaf number ran out (csrc/nm_index.hip): the
-            # occupancy index, and with it every feature of that scale, is incomplete
-            from nimrud_amd import _ffi
-            raise _ffi.NimrudHipError("occupancy index build timed out at scale(s) %s"
-                                      % np.flatnonzero(host[:n_scales, 0] < 0).tolist())
+        rt.check_async(wait=True)        # an unusable lattice, an index that timed out or overflowed
         if strict and host[:n_scales, 1].any():
             raise FloatingPointError(
                 "%d neighborhoods have fewer than 2 voxels; their covariance is undefined "

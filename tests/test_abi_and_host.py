@@ -45,7 +45,8 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_ffi.NmLattice) == 56
     assert _ffi.NmLattice.edge.offset == 24 and _ffi.NmLattice.widths.offset == 32
     assert _ffi.NmLattice.shifts.offset == 44
-    assert ctypes.sizeof(_ffi.NmForest) == 9 * 8 + 6 * 4
+    assert ctypes.sizeof(_ffi.NmForest) == 10 * 8 + 6 * 4
+    assert _ffi.NmForest.d_packed8.offset == 9 * 8 + 6 * 4
 
 
 def test_workspace_queries_need_no_gpu():
@@ -55,6 +56,10 @@ def test_workspace_queries_need_no_gpu():
     big = lib.nm_scale_workspace_bytes(100000, 100000, ctypes.byref(lat))
     assert 0 < small < big
     assert lib.nm_voxelize_workspace_bytes(1000) < lib.nm_voxelize_workspace_bytes(1000000)
+    # the ladder's workspace depends on the point counts and the number of scales only
+    assert 0 < lib.nm_ladder_workspace_bytes(1000, 1000, 2) < lib.nm_ladder_workspace_bytes(1000, 1000, 5)
+    assert lib.nm_ladder_workspace_bytes(1000, 1000, 33) == 0
+    assert lib.nm_halo_workspace_bytes(0, 8) < lib.nm_halo_workspace_bytes(100000, 8)
 
 
 def test_no_gpu_is_a_loud_error():

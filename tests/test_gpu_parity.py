@@ -20,6 +20,11 @@ from oracle import nimrud_oracle as oracle
 
 pytestmark = pytest.mark.gpu
 
+
+def _device_runtime():
+    from nimrud_amd import device
+    return device.get_runtime()
+
 PIPELINE_FIXTURES = ["g1_uniform.npz", "g2_scene.npz", "g3_offset.npz", "g4_lattice.npz"]
 
 
@@ -623,7 +628,17 @@ def test_ladder_argument_checks():
     with pytest.raises(ValueError):                           # more scales than one call takes
         multiscale.process_gpu(dev, dev, [0.1] * 33, [0.3] * 33)
     with pytest.raises(ValueError):                           # 64 address bits are not enough
-        multiscale.process_gpu(dev, dev, [1e-9], [3e-9])
+        multiscale.process_single_core(pts, pts, [1e-9], [3e-9])       # geometry.py:59-60
+    # the GPU-resident form only enqueues work (the lattices are built on the device): the same failure
+    # surfaces at the next synchronisation point, once, and the context carries on
+    multiscale.process_gpu(dev, dev, [0.1, 1e-9], [0.3, 3e-9])
+    with pytest.raises(ValueError, match="too small"):
+        _device_runtime().check_async(wait=True)
+    _device_runtime().check_async(wait=True)
+    with pytest.raises(ValueError):                           # a cloud without extent on an axis
+        flat = pts.copy()
+        flat[:, 2] = 1.0
+        multiscale.process_single_core(flat, flat, [0.1], [0.3])
     with pytest.raises(ValueError):
         multiscale.process_gpu(dev, dev, [0.1], [0.3], cov_out=torch.zeros((3000, 5), dtype=torch.float64,
                                                                            device="cuda"))
@@ -635,24 +650,104 @@ def test_ladder_argument_checks():
     assert_features_close(got, oracle.process_fast(pts, pts, [0.1], [0.3]), pts)
 
 
-def test_pipelined_ladder_is_bit_identical():
-    """nm_set_overlap(1): the indexes are built on the library's auxiliary stream while the caller's
-    stream runs the search kernels.  same bits, same counters."""
+def test_device_built_lattices_match_the_hosts():
+    # nm_ladder_features builds every lattice on the device (geometry.py:37-64: min - e/2, widths =
+    # ceil(log2(span/e))); nm_multiscale_features takes them from the host, where numpy does that arithmetic.
+    # same lattices -> bit-identical features, for extents that land exactly on powers of two as well
+    # (width = log2 exactly) and at UTM-like offsets.
+    import ctypes
+    from nimrud_amd import _ffi, device as nm_device
+    rs = np.random.RandomState(707)
+    rt = _device_runtime()
+    cases = []
+    for k in range(6):
+        cases.append(rs.rand(20000, 3) * rs.uniform(1.0, 40.0, 3) + rs.uniform(-50, 50, 3))
+    exact = rs.rand(20000, 3) * np.array([12.7, 6.3, 3.1])
+    exact[0] = 0.0
+    exact[1] = [12.7, 6.3, 3.1]                       # span/e = 2^7, 2^6, 2^5 at e = 0.1 (+ one cell)
+    cases.append(exact)
+    cases.append(cases[0] + np.array([4.0e5, 5.1e6, 300.0]))
+    for pts in cases:
+        pts = np.ascontiguousarray(pts)
+        edges, radii = [0.1, 0.2, 0.45], [0.3, 0.6, 0.9]
+        dev = torch.from_numpy(pts).cuda()
+        got, info = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
+        # the host-lattice entry point with numpy's lattices
+        lats = (_ffi.NmLattice * 3)()
+        for s, e in enumerate(edges):
+            mc, _, widths, _ = geometry.lattice_parameters(pts.min(0), pts.max(0), e)
+            lat = geometry.make_nm_lattice(mc, e, widths)
+            ctypes.memmove(ctypes.byref(lats[s]), ctypes.byref(lat), ctypes.sizeof(_ffi.NmLattice))
+        rad = (ctypes.c_double * 3)(*radii)
+        want = torch.empty_like(got)
+        nbytes = rt.lib.nm_multiscale_workspace_bytes(len(pts), len(pts), lats, 3)
+        work = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+        rt.check(rt.lib.nm_multiscale_features(
+            rt.ctx, nm_device.ptr(dev), len(pts), 3, nm_device.ptr(dev), len(pts), 3, lats, rad, 3,
+            nm_device.ptr(want), 12, None, nm_device.ptr(work), work.numel(), rt.stream()))
+        assert torch.equal(got, want)
+        for s, e in enumerate(edges):
+            lat = oracle.Lattice(pts, e)
+            assert info[s].voxels == len(np.unique(lat.coordinate_to_address(pts)))
+
+
+def test_scale_loop_and_per_scale_launches_are_bit_identical():
+    """nm_set_fuse_scales: consecutive scales with one radius/edge ratio run in one launch of the search
+    kernel (the wave walks the scales) or in one launch each.  same bits, same counters.  (nm_set_overlap
+    is accepted and ignored since ABI 5.)"""
     from nimrud_amd import device
     rt = device.get_runtime()
     pts, _ = synth.scene_cloud(300000, extent=35.0, n_poles=40, n_spheres=10, seed=606)
-    edges, radii = [0.05, 0.10, 0.20, 0.40, 0.80], [0.15, 0.30, 0.60, 1.20, 2.40]
+    # 0.1/0.3 and 0.2/0.6 share a window, 0.4/1.0 (ratio 2.5) does not, 0.8/2.4 again: three launches
+    edges, radii = [0.10, 0.20, 0.40, 0.80], [0.30, 0.60, 1.00, 2.40]
     dev = torch.from_numpy(pts).cuda()
     a, ia = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
     try:
+        rt.check(rt.lib.nm_set_fuse_scales(rt.ctx, 0))
         rt.check(rt.lib.nm_set_overlap(rt.ctx, 1))
-        for _ in range(3):
+        for _ in range(2):
             b, ib = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
             assert torch.equal(a, b)
             assert [(x.voxels, x.leaves, x.degenerate) for x in ia] == \
                    [(x.voxels, x.leaves, x.degenerate) for x in ib]
     finally:
+        rt.check(rt.lib.nm_set_fuse_scales(rt.ctx, 1))
         rt.check(rt.lib.nm_set_overlap(rt.ctx, 0))
+    want = oracle.process_fast(pts, pts, edges, radii)
+    assert_features_close(a.cpu().numpy(), want, pts)
+
+
+def test_forest_behind_the_last_scale_matches_the_stand_alone_evaluator():
+    # nm_set_forest_output: labels and probabilities out of the search kernel's epilogue against
+    # nm_forest_eval on the finished matrix and against the oracle's forest walk; also with the kNN fallback
+    # on (rows are rewritten after the last kernel: the library must evaluate the finished matrix) and with a
+    # last scale of unusual ratio (generic kernel: no epilogue to carry the forest).
+    pts, labels = synth.scene_cloud(80000, extent=16.0, n_poles=14, n_spheres=5, seed=153, five_class=True)
+    dev = torch.from_numpy(pts).cuda()
+    for edges, radii, kw in (([0.1, 0.2, 0.4], [0.3, 0.6, 1.2], {}),
+                             ([0.1, 0.2, 0.4], [0.3, 0.6, 1.2], {"knn_min": 6}),
+                             ([0.1, 0.2, 0.1], [0.3, 0.6, 0.62], {}),
+                             ([0.25], [0.75], {})):
+        feats = multiscale.process_gpu(dev, dev, edges, radii, **kw)
+        tr, va = classification.balanced_split(labels, seed=1)
+        model, clf = classification.train_forest(feats[torch.from_numpy(tr).cuda()], labels[tr],
+                                                 n_estimators=12, max_depth=9, n_jobs=4)
+        label, proba, feats2 = classification.classify_cloud(dev, edges, radii, model, want_proba=True, **kw)
+        assert torch.equal(feats, feats2)
+        label0, proba0, _ = classification.classify_cloud(dev, edges, radii, model, fused=False,
+                                                          want_proba=True, **kw)
+        assert torch.equal(label, label0) and torch.equal(proba, proba0)
+        omodel = classification.ForestModel.flatten_sklearn(clf)
+        rows = np.arange(0, len(pts), 17)
+        want = oracle.forest_predict_proba(omodel, feats.cpu().numpy()[rows])
+        assert np.abs(proba.cpu().numpy()[rows] - want).max() <= 1e-15
+        assert np.array_equal(label.cpu().numpy()[rows], want.argmax(1))
+    # a forest the epilogue cannot take (more features than 20) falls back to the stand-alone evaluator
+    edges6, radii6 = [0.1, 0.15, 0.2, 0.3, 0.4, 0.6], [0.3, 0.45, 0.6, 0.9, 1.2, 1.8]
+    feats = multiscale.process_gpu(dev, dev, edges6, radii6)
+    model, clf = classification.train_forest(feats[::7], labels[::7], n_estimators=8, max_depth=8, n_jobs=4)
+    label, _ = classification.classify_cloud(dev, edges6, radii6, model)
+    assert np.array_equal(model.classes[label.cpu().numpy()[::5]], clf.predict(feats.cpu().numpy()[::5]))
 
 
 def test_plain_c_host_through_the_c_abi(tmp_path):
@@ -953,11 +1048,14 @@ def test_config5_full_size_end_to_end(golden):
     # sklearn's labels on the oracle's features: a row can only differ where a feature rounds across a
     # split threshold after the fp32 cast
     assert (model.classes[got[rows]] != g["label"]).sum() <= 2
-    # stand-alone evaluation of the finished matrix: every one of the 1e7 labels identical
+    # the forest ran inside the search kernel, behind each row's last scale.  stand-alone evaluation of the
+    # finished matrix (nm_forest_eval): every one of the 1e7 labels identical
     label2 = model.predict(feats)
     assert torch.equal(torch.as_tensor(model.classes, device="cuda")[label.to(torch.int64)], label2)
     proba = model.predict_proba(feats[:100000])
     assert torch.equal(proba.argmax(1).to(torch.int32), label[:100000])
+    label3, _ = classification.classify_cloud(dev, edges, radii, model, fused=False)
+    assert torch.equal(label, label3)
     assert (got == labels).mean() > 0.95
 
 
