@@ -637,8 +637,8 @@ def test_ladder_argument_checks():
     _device_runtime().check_async(wait=True)
     with pytest.raises(ValueError):                           # a cloud without extent on an axis
         flat = pts.copy()
-        flat[:, 2] = 1.0
-        multiscale.process_single_core(flat, flat, [0.1], [0.3])
+        flat[:, 2] = 1.0                                      # span/e = 1 exactly -> width 0 (geometry.py:74)
+        multiscale.process_single_core(flat, flat, [0.25], [0.75])
     with pytest.raises(ValueError):
         multiscale.process_gpu(dev, dev, [0.1], [0.3], cov_out=torch.zeros((3000, 5), dtype=torch.float64,
                                                                            device="cuda"))
