@@ -364,9 +364,10 @@ typedef struct nm_forest {
     /* optional compact layout of the same renumbered nodes (needs d_leaf_value and d_packed_roots too, and
      * n_features <= 32): one 8-byte record per node {float threshold; uint32 packed}.  the threshold is the
      * largest fp32 value not above the fp64 threshold - sklearn compares the fp32-cast feature with the fp64
-     * threshold, and x_f32 <= t_f64 holds exactly when x_f32 <= that value.  packed: bit 31 set = leaf, bits
-     * 30..0 its row in d_leaf_value; else bits 30..5 the left child's record, bits 4..0 the feature.
-     * preferred by nm_forest_eval when present; required by nm_set_forest_output.                       */
+     * threshold, and x_f32 <= t_f64 holds exactly when x_f32 <= that value.  packed: bits 30..13 = the left
+     * child's record (so at most 2^18 nodes), bits 12..8 the feature, bits 7..0 zero; a leaf has bit 31 set,
+     * its row in d_leaf_value in bits 30..13 and the rest zero.  preferred by nm_forest_eval when present; required by
+     * nm_set_forest_output.                                                                             */
     const void*    d_packed8;
 } nm_forest;
 

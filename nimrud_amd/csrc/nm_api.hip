@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256) void k_forest_eval_packed8(ForestDev F, const 
 #pragma unroll
             for (int g = 0; g < NM_FOREST_TREES; ++g) {
                 if (!(rec[g].y >> 31)) {
-                    const float v = xs[(rec[g].y & 31u) * 256 + threadIdx.x];
-                    rec[g] = F.nodes[(rec[g].y >> 5) + (v <= __uint_as_float(rec[g].x) ? 0u : 1u)];
+                    const float v = xs[((rec[g].y >> 8) & 31u) * 256 + threadIdx.x];
+                    rec[g] = F.nodes[(rec[g].y >> 13) + (v <= __uint_as_float(rec[g].x) ? 0u : 1u)];
                     any = true;
                 }
             }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_forest_eval_packed8(ForestDev F, const 
 #pragma unroll
         for (int g = 0; g < NM_FOREST_TREES; ++g) {
             if (t0 + g >= F.n_trees) break;
-            const double* val = F.leaf_value + (int64_t)(rec[g].y & 0x7FFFFFFFu) * F.n_classes;
+            const double* val = F.leaf_value + (int64_t)((rec[g].y >> 13) & 0x3FFFFu) * F.n_classes;
 #pragma unroll
             for (int c = 0; c < NM_MAX_CLASSES; ++c)
                 if (c < F.n_classes) acc[c] += val[c];

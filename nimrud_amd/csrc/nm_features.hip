@@ -636,10 +636,13 @@ __device__ __forceinline__ void nm_lane_generic(const ScaleArgs& A, const Lattic
 // time.  the 64 lanes of a wave are neighbours in space: their paths mostly coincide, so a node fetch
 // touches few cache lines.  node = 8 bytes {fp32 threshold, packed}; x_f32 <= threshold_f64 is evaluated as
 // x_f32 <= largest fp32 not above the threshold, which is the same predicate.
-constexpr int NM_FUSED_FOREST_TREES = 8;        // descents in flight per lane
+// node = {fp32 threshold, packed}.  internal: left child << 13 | feature << 8, so that
+// (packed & 0x1F00) | lane * 4 already is the LDS byte address of this lane's value of the feature;
+// leaf: bit 31 | row of its class distribution << 13 (bits 8..12 clear: a leaf "reads" feature 0, harmlessly).
+constexpr int NM_FOREST_GROUP = 8;      // trees per group; two groups (16 descents) in flight per lane
 
-__device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, float* xs, int lane, bool have,
-                                                   uint32_t qi)
+__device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, const uint2* __restrict__ nodes,
+                                                   float* xs, int lane, bool have, uint32_t qi)
 {
     const ForestDev& F = A.F;
     if (have) {
@@ -648,33 +651,64 @@ __device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, float* xs
     }
     lds_fence();
     if (!have) return;
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    const char* xsb = (const char*)xs;
     double acc[NM_FUSED_FOREST_CLASSES];
 #pragma unroll
     for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c) acc[c] = 0.0;
-    for (int t0 = 0; t0 < F.n_trees; t0 += NM_FUSED_FOREST_TREES) {
-        uint2 rec[NM_FUSED_FOREST_TREES];
+    for (int t0 = 0; t0 < F.n_trees; t0 += 2 * NM_FOREST_GROUP) {
+        // a descent is a chain of dependent steps - LDS read of the feature, compare, node fetch from L2.  the
+        // steps of one level are issued for all trees of both groups before anything is waited for: sixteen
+        // LDS reads, then sixteen node fetches in flight per lane.
+        uint2 ra[NM_FOREST_GROUP], rb[NM_FOREST_GROUP];
 #pragma unroll
-        for (int g = 0; g < NM_FUSED_FOREST_TREES; ++g) {
-            const int t = t0 + g < F.n_trees ? t0 + g : F.n_trees - 1;
-            rec[g] = F.nodes[F.roots[t]];
+        for (int g = 0; g < NM_FOREST_GROUP; ++g) {
+            const int ta = t0 + g < F.n_trees ? t0 + g : F.n_trees - 1;
+            const int tb = t0 + NM_FOREST_GROUP + g < F.n_trees ? t0 + NM_FOREST_GROUP + g : F.n_trees - 1;
+            ra[g] = nodes[F.roots[ta]];
+            rb[g] = nodes[F.roots[tb]];
         }
-        bool any = true;
-        while (any) {
-            any = false;
+        // (a branch-free form - finished trees re-fetch their leaf, 7 vector instructions per tree and level,
+        // no jumps - measured slower, 2.35 against 2.05 ms for 10 M rows x 32 trees: depths differ, and it
+        // pays the deepest tree's levels for all sixteen)
+        for (;;) {
+            float va[NM_FOREST_GROUP], vb[NM_FOREST_GROUP];
 #pragma unroll
-            for (int g = 0; g < NM_FUSED_FOREST_TREES; ++g) {
-                if (!(rec[g].y >> 31)) {
-                    const float v = xs[(rec[g].y & 31u) * 64 + lane];
-                    const uint32_t left = rec[g].y >> 5;
-                    rec[g] = F.nodes[left + (v <= __uint_as_float(rec[g].x) ? 0u : 1u)];
+            for (int g = 0; g < NM_FOREST_GROUP; ++g)
+                va[g] = *(const float*)(xsb + ((ra[g].y & 0x1F00u) | lane4));
+#pragma unroll
+            for (int g = 0; g < NM_FOREST_GROUP; ++g)
+                vb[g] = *(const float*)(xsb + ((rb[g].y & 0x1F00u) | lane4));
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < NM_FOREST_GROUP; ++g) {
+                if ((int32_t)ra[g].y >= 0) {
+                    ra[g] = nodes[(ra[g].y >> 13) + (va[g] <= __uint_as_float(ra[g].x) ? 0u : 1u)];
                     any = true;
                 }
             }
+#pragma unroll
+            for (int g = 0; g < NM_FOREST_GROUP; ++g) {
+                if ((int32_t)rb[g].y >= 0) {
+                    rb[g] = nodes[(rb[g].y >> 13) + (vb[g] <= __uint_as_float(rb[g].x) ? 0u : 1u)];
+                    any = true;
+                }
+            }
+            if (!any) break;
+        }
+        // the votes are added in tree order, like sklearn's accumulate-then-divide
+#pragma unroll
+        for (int g = 0; g < NM_FOREST_GROUP; ++g) {
+            if (t0 + g >= F.n_trees) break;
+            const double* val = F.leaf_value + (int64_t)((ra[g].y >> 13) & 0x3FFFFu) * F.n_classes;
+#pragma unroll
+            for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)
+                if (c < F.n_classes) acc[c] += val[c];
         }
 #pragma unroll
-        for (int g = 0; g < NM_FUSED_FOREST_TREES; ++g) {
-            if (t0 + g >= F.n_trees) break;
-            const double* val = F.leaf_value + (int64_t)(rec[g].y & 0x7FFFFFFFu) * F.n_classes;
+        for (int g = 0; g < NM_FOREST_GROUP; ++g) {
+            if (t0 + NM_FOREST_GROUP + g >= F.n_trees) break;
+            const double* val = F.leaf_value + (int64_t)((rb[g].y >> 13) & 0x3FFFFu) * F.n_classes;
 #pragma unroll
             for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)
                 if (c < F.n_classes) acc[c] += val[c];
@@ -696,11 +730,13 @@ __device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, float* xs
     if (F.label) F.label[qi] = best;
 }
 
-// LOOP = false: exactly one scale per launch (A.s_begin) - the form every register count in DESIGN.md is
-// quoted for.  LOOP = true: the wave walks the scales [A.s_begin, A.s_end).
+#ifndef NM_SEARCH_ATTR
+#define NM_SEARCH_ATTR
+#endif
 template <int W, bool RHO3, bool FOREST, bool LOOP>
-__global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTable RT,
-                                                       const ScaleDev* __restrict__ scales)
+__global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs A, RowBoundTable RT,
+                                                       const ScaleDev* __restrict__ scales,
+                                                       const uint2* __restrict__ forest_nodes)
 {
     static_assert(W >= 3 && W <= 9 && (W & 1), "LUT kernel covers W = 3,5,7,9");
     static_assert(!RHO3 || W == 7, "the compile-time table is for W = 7");
@@ -1067,7 +1103,7 @@ __global__ __launch_bounds__(64) void k_scale_features(ScaleArgs A, RowBoundTabl
             have = qi < A.nq;
         }
         lds_fence();                         // the last pass has read the row buffer
-        nm_forest_epilogue(A, (float*)lds_raw, lane, have, qi);
+        nm_forest_epilogue(A, forest_nodes, (float*)lds_raw, lane, have, qi);
     }
 }
 
@@ -1136,7 +1172,6 @@ __global__ void k_publish_info_all(const ScaleDev* __restrict__ ladder, int32_t 
 // voxel centres within rk (rk2 = rk*rk).  one lane per query; the lane walks the index leaves that
 // intersect the cube around its home cell that contains the ball of radius rk.  exact fp64 distances in
 // the reference's operation order, ties broken by the smaller voxel address.
-constexpr int NM_KNN_MAX = 16;
 
 struct KnnArgs {
     ScaleArgs S;
@@ -1184,8 +1219,15 @@ __global__ __launch_bounds__(256) void k_knn_compact(const unsigned long long* _
     }
 }
 
+// KMAX: slots of the per-lane best list (8 serves k <= 8: half the insertion network and half its registers).
+// CodeT: the tie-break key - the candidate's cell offsets from the home cell, biased, z high / x low (the
+// order of the reference's voxel address) - 32 bits while the cube stays within +-511 cells, else 64.
+template <int KMAX, typename CodeT>
 __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
 {
+    constexpr int BITS = sizeof(CodeT) == 4 ? 10 : 11;
+    constexpr int32_t BIAS = 1 << (BITS - 1);
+    constexpr CodeT CODE_MAX = sizeof(CodeT) == 4 ? (CodeT)0x7FFFFFFF : (CodeT)INT64_MAX;
     const ScaleArgs& A = K.S;
     const ScaleDev* __restrict__ SD = A.scales + K.scale;
     if (!SD->valid) return;
@@ -1203,8 +1245,8 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
     const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
     const int32_t hz = nm_clamp_cell(nm_cell_f(qz, L.min_z, L.edge));
 
-    double bd[NM_KNN_MAX];
-    int64_t bc[NM_KNN_MAX];      // address-like code of the voxel: tie break and offsets
+    double bd[KMAX];
+    CodeT bc[KMAX];              // address-like code of the voxel: tie break and offsets
     double kth_best = INFINITY;  // bd[k-1]: a candidate beyond it cannot be among the k nearest
     int32_t found = 0;
     // two stages: a small cube first - most sparse neighborhoods find their k voxels just outside the
@@ -1212,9 +1254,9 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
     // a cube of half-width S is at least S + 1/2 cells away).
     for (int stage = 0; stage < 2; ++stage) {
 #pragma unroll
-    for (int t = 0; t < NM_KNN_MAX; ++t) {
+    for (int t = 0; t < KMAX; ++t) {
         bd[t] = INFINITY;
-        bc[t] = INT64_MAX;
+        bc[t] = CODE_MAX;
     }
     found = 0;
     kth_best = INFINITY;
@@ -1241,11 +1283,15 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
                     if (gz < z_lo || gz > z_hi) continue;
                     double d = qz - nm_centre(gz, L.min_z, L.edge, L.half_edge);
                     const double dz2 = d * d;
+                    // the eight row words of this z layer in two 16-byte loads
+                    const uint4 w0 = *(const uint4*)(I.leaf + (size_t)leaf * NM_LEAF_WORDS + lz * 8);
+                    const uint4 w1 = *(const uint4*)(I.leaf + (size_t)leaf * NM_LEAF_WORDS + lz * 8 + 4);
+                    const uint32_t words[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
                     for (int32_t ly = 0; ly < 8; ++ly) {
                         const int32_t gy = (sby << NM_SBY_BITS) + ly;
-                        if (gy < y_lo || gy > y_hi) continue;
-                        uint32_t word = I.leaf[(size_t)leaf * NM_LEAF_WORDS + lz * 8 + ly] & xmask;
-                        if (!word) continue;
+                        uint32_t word = words[ly] & xmask;
+                        if (gy < y_lo || gy > y_hi || !word) continue;
                         d = qy - nm_centre(gy, L.min_y, L.edge, L.half_edge);
                         const double dy2 = d * d;
                         while (word) {
@@ -1259,20 +1305,20 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
                             if (cd > kth_best) continue;      // cannot be among the k nearest
                             // offsets from the home cell, biased, z high / x low: the same order as
                             // the reference's voxel address, which is the tie break
-                            int64_t cc = ((int64_t)(gz - hz + 1024) << 22) |
-                                         ((int64_t)(gy - hy + 1024) << 11) | (int64_t)(gx - hx + 1024);
+                            CodeT cc = ((CodeT)(gz - hz + BIAS) << (2 * BITS)) |
+                                       ((CodeT)(gy - hy + BIAS) << BITS) | (CodeT)(gx - hx + BIAS);
 #pragma unroll
-                            for (int t = 0; t < NM_KNN_MAX; ++t) {
+                            for (int t = 0; t < KMAX; ++t) {
                                 const bool before = cd < bd[t] || (cd == bd[t] && cc < bc[t]);
                                 const double td = before ? bd[t] : cd;
-                                const int64_t tc = before ? bc[t] : cc;
+                                const CodeT tc = before ? bc[t] : cc;
                                 bd[t] = before ? cd : bd[t];
                                 bc[t] = before ? cc : bc[t];
                                 cd = td;
                                 cc = tc;
                             }
 #pragma unroll
-                            for (int t = 0; t < NM_KNN_MAX; ++t)
+                            for (int t = 0; t < KMAX; ++t)
                                 if (t == K.k - 1) kth_best = bd[t];
                         }
                     }
@@ -1280,7 +1326,7 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
             }
     double kth = INFINITY;
 #pragma unroll
-    for (int t = 0; t < NM_KNN_MAX; ++t)
+    for (int t = 0; t < KMAX; ++t)
         if (t == K.k - 1) kth = bd[t];
     const double reach = ((double)S + 0.5 - 1e-6) * L.edge;
     if (S >= K.max_shell || kth <= reach * reach) break;
@@ -1288,11 +1334,11 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
     const int32_t use = found < K.k ? found : K.k;
     double n = 0, sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
 #pragma unroll
-    for (int t = 0; t < NM_KNN_MAX; ++t) {
+    for (int t = 0; t < KMAX; ++t) {
         if (t < use) {
-            const double ox = (double)((int32_t)(bc[t] & 0x7FF) - 1024);
-            const double oy = (double)((int32_t)((bc[t] >> 11) & 0x7FF) - 1024);
-            const double oz = (double)((int32_t)(bc[t] >> 22) - 1024);
+            const double ox = (double)((int32_t)(bc[t] & ((1 << BITS) - 1)) - BIAS);
+            const double oy = (double)((int32_t)((bc[t] >> BITS) & ((1 << BITS) - 1)) - BIAS);
+            const double oz = (double)((int32_t)(bc[t] >> (2 * BITS)) - BIAS);
             n += 1.0;
             sx += ox; sy += oy; sz += oz;
             sxx += ox * ox; sxy += ox * oy; sxz += ox * oz;
@@ -1356,7 +1402,15 @@ static int launch_knn_fallback(nm_ctx* ctx, const ScaleArgs& A, int scale, doubl
     double shells = ceil(rk / edge + 0.5);
     if (shells > 1000.0) shells = 1000.0;
     K.max_shell = (int32_t)shells;
-    k_knn_fallback<<<(int)((A.n_slots + 63) / 64), 64, 0, s>>>(K);
+    const int blocks = (int)((A.n_slots + 63) / 64);
+    const bool small_codes = K.max_shell <= 500;        // +-511 cells fit the 10-bit fields
+    if (K.k <= 8) {
+        if (small_codes) k_knn_fallback<8, int32_t><<<blocks, 64, 0, s>>>(K);
+        else k_knn_fallback<8, int64_t><<<blocks, 64, 0, s>>>(K);
+    } else {
+        if (small_codes) k_knn_fallback<16, int32_t><<<blocks, 64, 0, s>>>(K);
+        else k_knn_fallback<16, int64_t><<<blocks, 64, 0, s>>>(K);
+    }
     return NM_OK;
 }
 
@@ -1381,13 +1435,13 @@ static void launch_table_kernel(const ScaleArgs& A, double rho, int W, int block
     // here are the pruned ones, lattices that cannot use them take the per-lane path inside the kernel
     const bool rho3 = W == 7 && fabs(rho - 3.0) < 1e-9;
     switch (W) {
-        case 3: k_scale_features<3, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, true), A.scales); break;
-        case 5: k_scale_features<5, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, true), A.scales); break;
+        case 3: k_scale_features<3, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, true), A.scales, A.F.nodes); break;
+        case 5: k_scale_features<5, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, true), A.scales, A.F.nodes); break;
         case 7:
-            if (rho3) k_scale_features<7, true, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3, A.scales);
-            else k_scale_features<7, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, true), A.scales);
+            if (rho3) k_scale_features<7, true, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3, A.scales, A.F.nodes);
+            else k_scale_features<7, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, true), A.scales, A.F.nodes);
             break;
-        default: k_scale_features<9, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, true), A.scales); break;
+        default: k_scale_features<9, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, true), A.scales, A.F.nodes); break;
     }
 }
 

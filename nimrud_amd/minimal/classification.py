@@ -97,9 +97,10 @@ class ForestModel(object):
         nm_forest::d_packed8).  sklearn sends a row left when (double)(float)x <= threshold; for an fp32
         x that is the same as x <= the largest fp32 not above the threshold, so the threshold is stored
         rounded DOWN to fp32 and the comparison done in fp32: bit-identical decisions, half the bytes per
-        node visit.  packed: bit 31 = leaf, then the leaf's row; else left child << 5 | feature.
-        None when the forest does not fit the fields (more than 32 features or 2^26 nodes)."""
-        if n_features > 32 or len(rec) >= (1 << 26):
+        node visit.  packed: left child << 13 | feature << 8 (the kernel ORs its lane's byte offset into the
+        low bits and has the LDS address of the feature value); a leaf has bit 31 set and its row << 13.
+        None when the forest does not fit the fields (more than 32 features or 2^18 nodes)."""
+        if n_features > 32 or len(rec) >= (1 << 18):
             return None
         thr = rec["threshold"].astype(np.float64)
         t32 = thr.astype(np.float32)
@@ -107,9 +108,9 @@ class ForestModel(object):
         t32[above] = np.nextafter(t32[above], np.float32(-np.inf))
         assert np.all(t32.astype(np.float64) <= thr)
         leaf = rec["left"] < 0
-        packed = np.where(leaf, np.uint32(1 << 31) | rec["feature"].astype(np.uint32),
-                          (rec["left"].astype(np.uint32) << np.uint32(5)) |
-                          rec["feature"].astype(np.uint32)).astype(np.uint32)
+        packed = np.where(leaf, np.uint32(1 << 31) | (rec["feature"].astype(np.uint32) << np.uint32(13)),
+                          (rec["left"].astype(np.uint32) << np.uint32(13)) |
+                          (rec["feature"].astype(np.uint32) << np.uint32(8))).astype(np.uint32)
         out = np.zeros(len(rec), dtype=np.dtype([("threshold", "<f4"), ("packed", "<u4")]))
         out["threshold"] = t32
         out["packed"] = packed

@@ -342,15 +342,15 @@ def process_fast(query_cloud, search_cloud, edge_lengths, radii, workers=1, boun
          for e, r in zip(edge_lengths, radii)], axis=1)
 
 
-def one_scale_knn(query_cloud, search_cloud, edge_length, radius, k_min, radius_factor=3.0):
+def one_scale_knn(query_cloud, search_cloud, edge_length, radius, k_min, radius_factor=3.0, bounds=None):
     """BUILD-DEFINED extension (BASELINE config 4), no reference counterpart - parity for it is pinned
     by this function only.  like one_scale_fast, but a query whose radius neighborhood holds fewer than
     k_min voxels is re-evaluated on its k_min nearest voxel centres (cKDTree.query on the same voxel
     set) within radius_factor*radius; column 0 keeps the radius population."""
-    out = one_scale_fast(query_cloud, search_cloud, edge_length, radius)
+    out = one_scale_fast(query_cloud, search_cloud, edge_length, radius, bounds=bounds)
     query_xyz = np.asarray(query_cloud, dtype=np.float64)[:, :3]
     search_xyz = np.asarray(search_cloud, dtype=np.float64)[:, :3]
-    voxels = Lattice(search_xyz, edge_length).unique_voxels(search_xyz)
+    voxels = Lattice(search_xyz, edge_length, bounds=bounds).unique_voxels(search_xyz)
     tree = cKDTree(voxels, leafsize=LEAFSIZE)
     sparse = np.nonzero(out[:, 0] < k_min)[0]
     if len(sparse) == 0:

@@ -1124,6 +1124,39 @@ def test_config4_lidar_power_law_with_knn_fallback():
             assert_features_close(p[rows, 4 * s:4 * s + 4], want, pts)
 
 
+def test_config4_10m_every_row_against_the_c_oracle():
+    # config 4 at 10 M of its 50 M points (the full size is tools/config4_timing.py / tests/full_size_check.py,
+    # run by the builder): power-law density, 5 scales.  every one of the 5e7 point-scales against the plain-C
+    # oracle - populations bit-exact, features within the contract - and the kNN fallback (k_min = 8; it has no
+    # reference counterpart: parity unpinned by the reference, pinned by the build's oracle) against
+    # oracle.one_scale_knn on a sparse crop far from the scanner.
+    pts, _, edges, radii = synth.make_config("c4_lidar_50m", n=10_000_000)
+    k = synth.CONFIGS["c4_lidar_50m"]["knn_min"]
+    dev = torch.from_numpy(pts).cuda()
+    plain = multiscale.process_gpu(dev, dev, edges, radii).cpu().numpy()
+    for s, (e, r) in enumerate(zip(edges, radii)):
+        want_s = oracle.one_scale_c(pts, pts, e, r)
+        assert_features_close(plain[:, 4 * s:4 * s + 4], want_s, pts)
+    full = multiscale.process_gpu(dev, dev, edges, radii, knn_min=k, knn_radius_factor=3.0).cpu().numpy()
+    assert np.array_equal(plain[:, ::4], full[:, ::4])
+    dense = plain[:, 0] >= k
+    assert np.array_equal(plain[dense, :4], full[dense, :4]) and (~dense).mean() > 0.01
+    lo, hi = pts.min(0), pts.max(0)
+    d = np.abs(pts[:, :2] - np.array([100.0, 60.0]))
+    inner = np.all(d <= 6.0, axis=1)
+    outer = np.all(d <= 6.0 + 3.0 * 2.4 + 1.0, axis=1)
+    rows = np.nonzero(inner)[0][:4000]
+    assert len(rows) > 300
+    touched = 0
+    for s in (0, 1, 3):
+        # the oracle gets the crop plus a halo wider than the fallback's reach (3 r) and the GLOBAL extrema,
+        # so that its lattice is the cloud's
+        want = oracle.one_scale_knn(pts[rows], pts[outer], edges[s], radii[s], k, 3.0, bounds=(lo, hi))
+        assert_features_close(full[rows, 4 * s:4 * s + 4], want, pts)
+        touched += int((want[:, 0] < k).sum())
+    assert touched > 200
+
+
 def test_classify_cloud_end_to_end():
     # config 5 in miniature: features -> balanced split -> sklearn fit -> GPU forest -> confusion
     pts, labels = synth.scene_cloud(60000, extent=14.0, n_poles=12, n_spheres=4, seed=151)
