@@ -164,30 +164,36 @@ __device__ __forceinline__ void nm_eig3(double a00, double a01, double a02, doub
 // (full fp64 accuracy, no special-case handling; the library forms cost 12-14 instructions each).
 // (an fp32 eigenvector was tried: 5 % faster kernel, but the features then agree with LAPACK to 3e-7
 // instead of 1e-15 and l1 + l2 can exceed 1 by 1e-7 - not worth it.)
+// (the file is compiled with -ffp-contract=off because cells, centres and squared distances must round like
+// numpy's; none of that applies to the eigen-solve below, so it spells its fused multiply-adds out - a third
+// fewer instructions in the epilogue, and one rounding less per term)
+__device__ __forceinline__ double nm_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 __device__ __forceinline__ double nm_rcp_fast(double x)
 {
     double y = __builtin_amdgcn_rcp(x);     // v_rcp_f64: full exponent range, ~26 good bits
-    y = y * (2.0 - x * y);
-    return y * (2.0 - x * y);
+    y = y * nm_fma(-x, y, 2.0);
+    return y * nm_fma(-x, y, 2.0);
 }
 __device__ __forceinline__ double nm_rsqrt_fast(double x)
 {
     double y = __builtin_amdgcn_rsq(x);     // v_rsq_f64
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y * (1.5 - 0.5 * x * y * y);
+    const double hx = -0.5 * x;
+    y = y * nm_fma(hx * y, y, 1.5);
+    return y * nm_fma(hx * y, y, 1.5);
 }
 
 #ifndef NM_CUBIC_NEWTON_STEPS
-#define NM_CUBIC_NEWTON_STEPS 5   // quadratic from x0 = 2: error 0.27, 6e-2, 3e-3, 1e-5, 9e-11, < 1e-17
+#define NM_CUBIC_NEWTON_STEPS 4   // quadratic from the chord start: error 1.3e-2, 1e-4, 5e-9, < 1e-16 (one to spare)
 #endif
 __device__ __forceinline__ void nm_eig3_fast(double a00, double a01, double a02, double a11,
                                              double a12, double a22, double& l0, double& l1,
                                              double& l2)
 {
-    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double p1 = nm_fma(a01, a01, nm_fma(a02, a02, a12 * a12));
     const double q = (a00 + a11 + a22) * (1.0 / 3.0);
     const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
-    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    const double p2 = nm_fma(b00, b00, nm_fma(b11, b11, nm_fma(b22, b22, 2.0 * p1)));
     if (!(p2 > 0.0)) {
         l0 = l1 = l2 = q;
         return;
@@ -197,18 +203,24 @@ __device__ __forceinline__ void nm_eig3_fast(double a00, double a01, double a02,
     const double p = x6 * inv;
     const double c00 = b00 * inv, c11 = b11 * inv, c22 = b22 * inv;
     const double c01 = a01 * inv, c02 = a02 * inv, c12 = a12 * inv;
-    const double det = c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) +
-                       c02 * (c01 * c12 - c11 * c02);
+    const double m0 = nm_fma(c11, c22, -(c12 * c12));
+    const double m1 = nm_fma(c01, c22, -(c12 * c02));
+    const double m2 = nm_fma(c01, c12, -(c11 * c02));
+    const double det = nm_fma(c00, m0, nm_fma(-c01, m1, c02 * m2));
     const double r = fmin(fmax(det * 0.5, -1.0), 1.0);
     const bool top = r >= 0.0;
     const double ra = fabs(r);
-    double x = 2.0;
+    // with x = (lambda - q)/p the characteristic cubic is x^3 - 3x - 2r = 0; for r >= 0 its largest root, in
+    // [sqrt 3, 2], is the one well separated from the other two (r < 0: mirror image).  Newton from the
+    // chord between the end points (the root is concave in r: at most 1.3e-2 below it) is quadratic and
+    // well conditioned (f' >= 6 there); the approximate reciprocal only perturbs the step.
+    double x = nm_fma(ra, 2.0 - 1.7320508075688772, 1.7320508075688772);
 #pragma unroll
     for (int it = 0; it < NM_CUBIC_NEWTON_STEPS; ++it) {
         const double x2 = x * x;
-        const double f = x * (x2 - 3.0) - 2.0 * ra;
-        const double fp = 3.0 * x2 - 3.0;
-        x = x - f * __builtin_amdgcn_rcp(fp);
+        const double f = nm_fma(x, x2 - 3.0, -2.0 * ra);
+        const double fp = nm_fma(3.0, x2, -3.0);
+        x = nm_fma(-f, __builtin_amdgcn_rcp(fp), x);
     }
     // the other two roots of x^3 - 3x - 2r are -x/2 +- sqrt(3 (1 - x^2/4)).  with t = 1 - x^2/4
     // formed as (2-x)(2+x)/4 (the difference is exact) an error d in x becomes d / (2 sqrt t) in the
@@ -222,13 +234,13 @@ __device__ __forceinline__ void nm_eig3_fast(double a00, double a01, double a02,
         const double h = 0.5 * x;
         const double f0 = top ? x : h + s3;
         const double f1 = top ? s3 - h : h - s3;
-        l0 = q + p * f0;
-        l1 = q + p * f1;
-        l2 = 3.0 * q - l0 - l1;
+        l0 = nm_fma(p, f0, q);
+        l1 = nm_fma(p, f1, q);
+        l2 = nm_fma(3.0, q, -l0) - l1;
         return;
     }
     const double sx = top ? x : -x;
-    const double lam = q + p * sx;
+    const double lam = nm_fma(p, sx, q);
 
     // eigenvector of the scaled matrix C - sx*I: the cross product of two rows with the largest norm
     const double m00 = c00 - sx, m11 = c11 - sx, m22 = c22 - sx;
@@ -293,16 +305,16 @@ __device__ __forceinline__ void nm_features_from_moments(
     if (n < 1.0) return;
     // centroid (features.py:21-29): mean of the neighbor centres = home centre + e*(S1/n + dmin)
     const double inv_n = nm_rcp_fast(n);
-    double mx = ux - (sx * inv_n + dmin) * edge;
-    double my = uy - (sy * inv_n + dmin) * edge;
-    double mz = uz - (sz * inv_n + dmin) * edge;
-    const double d2 = mx * mx + my * my + mz * mz;
+    double mx = nm_fma(-nm_fma(sx, inv_n, dmin), edge, ux);
+    double my = nm_fma(-nm_fma(sy, inv_n, dmin), edge, uy);
+    double mz = nm_fma(-nm_fma(sz, inv_n, dmin), edge, uz);
+    const double d2 = nm_fma(mx, mx, nm_fma(my, my, mz * mz));
     out[1] = d2 > 0.0 ? d2 * nm_rsqrt_fast(d2) : 0.0;
     if (n < 2.0) return;   // covariance undefined: zeros (multiscale.py:4-5)
     // n*(n-1)/e^2 times the ddof=1 covariance (features.py:43), exact in integers:
     //   n*S2 - S1*S1^T.  normalised eigenvalues are invariant to that scale.
-    double a00 = n * sxx - sx * sx, a01 = n * sxy - sx * sy, a02 = n * sxz - sx * sz;
-    double a11 = n * syy - sy * sy, a12 = n * syz - sy * sz, a22 = n * szz - sz * sz;
+    double a00 = nm_fma(n, sxx, -(sx * sx)), a01 = nm_fma(n, sxy, -(sx * sy)), a02 = nm_fma(n, sxz, -(sx * sz));
+    double a11 = nm_fma(n, syy, -(sy * sy)), a12 = nm_fma(n, syz, -(sy * sz)), a22 = nm_fma(n, szz, -(sz * sz));
     double l0, l1, l2;
     nm_eig3_fast(a00, a01, a02, a11, a12, a22, l0, l1, l2);
     double tr = a00 + a11 + a22;      // = l0 + l1 + l2 (features.py:55)
