@@ -336,6 +336,7 @@ def main():
     _, info = multiscale.process_gpu(cloud, cloud, edges, radii, return_info=True) \
         if world == 1 else (None, plan.last_info())
     voxels = [i.voxels for i in info]
+    extra_passes = [i.extra_passes for i in info]
     n_local_search = cloud.shape[0] if world == 1 else plan.search_points()
 
     if world > 1:
@@ -439,6 +440,7 @@ def main():
                 "search_feature_kernel": ms[2] / args.steps,
             },
             "voxels_per_scale": voxels,
+            "extra_search_passes_per_scale": extra_passes,
         }
         if classify:
             f_ms = (elapsed / args.steps * 1e3 - features_only_ms) if features_only_ms else None

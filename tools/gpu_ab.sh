@@ -11,7 +11,7 @@ import json
 for w in ("c3","c5"):
     try:
         d=json.loads(open("$O/%s_${V}_$rep.json"%w).read().strip().splitlines()[-1])
-        print("$V rep$rep", w, "ms/step %.3f"%d["ms_per_step"], "search %.3f"%d["stage_ms_per_step"]["search_feature_kernel"], "index %.3f"%d["stage_ms_per_step"]["index_build"], "order %.3f"%d["stage_ms_per_step"]["cell_keys_and_sort"], "forest", d.get("forest",{}).get("ms_per_step"))
+        print("$V rep$rep", w, "ms/step %.3f"%d["ms_per_step"], "search %.3f"%d["stage_ms_per_step"]["search_feature_kernel"], "index %.3f"%d["stage_ms_per_step"]["index_build"], "order %.3f"%d["stage_ms_per_step"]["cell_keys_and_sort"], "forest", d.get("forest",{}).get("ms_per_step"), "extra passes", d.get("extra_search_passes_per_scale"))
     except Exception as e:
         print("$V", w, "ERR", e)
 PY
