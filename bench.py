@@ -375,10 +375,12 @@ def main():
         alg_bytes = float(np.sum([56.0 * nq + 8.0 * m for m in voxels])) / n_launch
         k_ms = ms[2] / max(launches.value, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(nq, "k_scale_features<7") if world == 1 else (None, None)
+        kernel_name = "k_scale_features<7, true, true" if (classify and fused) else "k_scale_features<7, true, false"
+        traffic, traffic_src = measured_traffic(nq, kernel_name) if world == 1 else (None, None)
         roofline = {
             "bound": "hbm",
-            "kernel": "k_scale_features<7>",
+            "kernel": kernel_name + ", ...> (search + moments + eigen-solve%s)" % (
+                " + forest epilogue" if (classify and fused) else ""),
             "scales_per_launch": n_scales / n_launch,
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
@@ -390,7 +392,7 @@ def main():
             "traffic_source": traffic_src,
             "alg_bytes_per_launch": alg_bytes,
             "kernel_ms_avg": k_ms,
-            "valu": valu_ceiling(nq * n_scales / n_launch, k_ms) if k_ms > 0 else None,
+            "valu": valu_ceiling(nq * n_scales / n_launch, k_ms) if (k_ms > 0 and not classify) else None,
             "note": "nominal bound is HBM (few bytes per unit of work); the binding ceiling is vector-ALU "
                     "issue, see `valu`: instructions per wave, fp64 flop per query and the fraction of the "
                     "fp64 vector peak they amount to at the measured query rate",

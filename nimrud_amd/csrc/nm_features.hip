@@ -642,10 +642,12 @@ __device__ __forceinline__ void nm_lane_generic(const ScaleArgs& A, const Lattic
 
 // ---- the classifier behind the last scale ---------------------------------------------------------------------
 // sklearn's RandomForestClassifier.predict / predict_proba (prototypes/apc.py:1463,1022,1034) on the row the
-// wave has just finished: the lane's 4S features are read back from the feature matrix - the lines this very
-// wave wrote moments ago, served by the XCD's L2 when the scales run in one launch - cast to fp32 as sklearn
-// does and staged in LDS ([feature][lane], conflict-free), then every lane walks the trees, eight at a
-// time.  the 64 lanes of a wave are neighbours in space: their paths mostly coincide, so a node fetch
+// wave has just finished: the lane's 4S features are read back from the feature matrix, cast to fp32 as
+// sklearn does and staged in LDS ([feature][lane], conflict-free) over the search phase's buffers, then
+// every lane walks the trees, sixteen at a time.  (measured: most of that read-back comes from HBM, not L2 -
+// the five scales' writes of other waves have pushed the lines out - 1.4 GB per 10 M rows.  keeping the
+// features in a dedicated LDS stage across the scale loop avoids it and is SLOWER, 2.36 against 2.0 ms: its
+// 5 KB per wave cost a wave of occupancy, and the tree walk lives on waves in flight.)  the 64 lanes of a wave are neighbours in space: their paths mostly coincide, so a node fetch
 // touches few cache lines.  node = 8 bytes {fp32 threshold, packed}; x_f32 <= threshold_f64 is evaluated as
 // x_f32 <= largest fp32 not above the threshold, which is the same predicate.
 // node = {fp32 threshold, packed}.  internal: left child << 13 | feature << 8, so that
