@@ -289,6 +289,8 @@ def main():
             return multiscale.process_gpu(cloud, cloud, edges, radii, out=out)
 
     fused = os.environ.get("NIMRUD_BENCH_FUSED_FOREST", "1") != "0"
+    if os.environ.get("NIMRUD_BENCH_FOREST_EPILOGUE"):
+        rt.check(rt.lib.nm_set_forest_mode(rt.ctx, int(os.environ["NIMRUD_BENCH_FOREST_EPILOGUE"])))
 
     def step():
         if model is None:

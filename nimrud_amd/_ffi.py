@@ -84,6 +84,7 @@ SIGNATURES = {
                             ctypes.POINTER(c_f64), c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_size,
                             c_ptr]),
     "nm_set_forest_output": (ctypes.c_int, [c_ptr, ctypes.POINTER(NmForest), c_ptr, c_i64, c_ptr]),
+    "nm_set_forest_mode": (ctypes.c_int, [c_ptr, ctypes.c_int]),
     "nm_field_workspace_bytes": (c_size, [c_i64, c_i64, _LATP, c_i32]),
     "nm_field_mean": (ctypes.c_int,
                       [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i32, _LATP, c_f64,

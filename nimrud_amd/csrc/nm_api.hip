@@ -160,6 +160,13 @@ extern "C" int nm_set_fuse_scales(nm_ctx* ctx, int enabled)
     return NM_OK;
 }
 
+extern "C" int nm_set_forest_mode(nm_ctx* ctx, int in_search_kernel)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    ctx->forest_epilogue = in_search_kernel != 0;
+    return NM_OK;
+}
+
 extern "C" int nm_set_forest_output(nm_ctx* ctx, const nm_forest* forest, double* d_proba,
                                     int64_t proba_stride, int32_t* d_label)
 {

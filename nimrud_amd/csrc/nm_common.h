@@ -66,6 +66,7 @@ struct nm_ctx {
     double knn_radius_factor = 3.0;
     // classifier behind the last scale of the ladder (nm_set_forest_output)
     bool forest_on = false;
+    bool forest_epilogue = true;     // true: inside the last search kernel; false: own launch behind it
     ForestDev forest{};
     int forest_features = 0;
     // consecutive scales with the same candidate window run in one launch (nm_set_fuse_scales)

@@ -744,6 +744,27 @@ __device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, const uin
     if (F.label) F.label[qi] = best;
 }
 
+// the same classifier as a kernel of its own, over the finished rows in the ladder's spatial order (the
+// lanes of a wave are neighbours in space, as in the epilogue) with all the registers and LDS to itself.
+// measured SLOWER than the epilogue (2.9 against 2.1 ms, 10 M rows x 32 trees): the tree walk is a chain of
+// dependent L1/L2 fetches and waits most of the time; in the epilogue it waits while other waves of the same
+// SIMD run their vector-ALU bound search.  used when the last kernel cannot carry the classifier (unusual
+// radius/edge ratio, kNN fallback on) or when nm_set_forest_mode asks for it.
+__global__ __launch_bounds__(64) void k_forest_ordered(ScaleArgs A, const uint2* __restrict__ nodes)
+{
+    __shared__ float xs[NM_FUSED_FOREST_FEATURES * 64];
+    const int lane = threadIdx.x;
+    const int64_t batch = nm_xcd_batch(blockIdx.x, gridDim.x);
+    const int64_t slot = batch * 64 + lane;
+    bool have = slot < A.n_slots;
+    uint32_t qi = 0;
+    if (have) {
+        qi = A.order[slot];
+        have = qi < A.nq;
+    }
+    nm_forest_epilogue(A, nodes, xs, lane, have, qi);
+}
+
 #ifndef NM_SEARCH_ATTR
 #define NM_SEARCH_ATTR
 #endif
@@ -1777,7 +1798,9 @@ static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, c
         A.sparse = ctx->knn_k > 0 ? (unsigned long long*)(w + S.knn.mask) : nullptr;
         A.sparse_words = S.knn.words;
         const bool want_forest = ctx->forest_on;
-        const bool in_kernel = want_forest && ctx->knn_k == 0;   // the fallback rewrites rows afterwards
+        // in the search kernel's epilogue only when asked to (nm_set_forest_mode) and when nothing rewrites
+        // rows afterwards (the kNN fallback does)
+        const bool in_kernel = want_forest && ctx->forest_epilogue && ctx->knn_k == 0;
         bool forest_done = false;
         if (want_forest) {
             A.F = ctx->forest;
@@ -1814,10 +1837,10 @@ static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, c
             i = j;
         }
         if (want_forest && !forest_done) {
-            // the last kernel could not carry the classifier (unusual window), or the kNN fallback has
-            // rewritten rows after it: evaluate on the finished matrix
-            rc = nm_forest_rows(ctx, ctx->forest, A.feat, A.fstride, A.nq, 4 * C.n_scales, s);
-            if (rc) return rc;
+            // the classifier as its own launch behind the last scale, rows taken in the spatial order
+            A.s_begin = 0;
+            A.s_end = C.n_scales;
+            k_forest_ordered<<<(int)((A.n_slots + 63) / 64), 64, 0, s>>>(A, A.F.nodes);
         }
     }
     nm_profile_mark(ctx, s);           // end of the "search" stage
