@@ -162,7 +162,11 @@ int nm_set_fuse_scales(nm_ctx* ctx, int enabled);
  * multi-GPU job has agreed on) are turned into every scale's lattice by a kernel - VoxelFilter.__init__ /
  * _calculate_shift, geometry.py:37-64, same arithmetic: min_corner = min - e/2, widths =
  * ceil(log2((max_corner - min_corner)/e)) - and all later kernels read the lattices from device memory.
- * nothing in the call waits for the device: it can be queued behind other work or captured in a hipGraph.
+ * nothing in the call waits for the device: it can be queued behind other work.  (it can also be captured in
+ * a hipGraph - the library records no event and queries none while its stream is capturing - and a replay is
+ * bit-identical to the eager call, on new data in the same buffers too: tools/graph_probe.py.  replay buys
+ * nothing measurable - the step is bound by its kernels, not by their launches - and back-to-back replays of
+ * the 10 M-point step stalled in that probe, so the product path does not use graphs.)
  * what a host-side VoxelFilter would have raised (geometry.py:59-60 "edge length is too small to address
  * this space"; no extent on an axis; a width outside the device path's [1,30]) is reported asynchronously
  * as NM_ERR_LATTICE through nm_check (see there).  the workspace depends on the point counts only.

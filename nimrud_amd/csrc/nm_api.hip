@@ -47,19 +47,28 @@ void nm_status_snapshot(nm_ctx* ctx, hipStream_t s)
     if (hipMemcpyAsync(ctx->h_status, ctx->d_status, NM_ST_WORDS * 4, hipMemcpyDeviceToHost, s) !=
         hipSuccess)
         return;
+    // inside a hipGraph capture the copy becomes a node of the graph - every replay refreshes the mirror -
+    // and no event is recorded (querying a captured event is illegal): nm_check(ctx, 1) after the caller has
+    // synchronised the replay reads the mirror as it stands
+    if (nm_capturing(s)) return;
     if (hipEventRecord(ctx->status_event, s) == hipSuccess) ctx->status_pending = true;
 }
 
 int nm_status_poll(nm_ctx* ctx, bool wait)
 {
     if (ctx->sticky) return ctx->sticky;
-    if (!ctx->status_pending) return NM_OK;
-    if (wait) {
-        if (hipEventSynchronize(ctx->status_event) != hipSuccess) return NM_OK;
-    } else if (hipEventQuery(ctx->status_event) != hipSuccess) {
-        return NM_OK;          // not there yet (or being captured): look again next time
+    if (ctx->status_pending) {
+        if (wait) {
+            if (hipEventSynchronize(ctx->status_event) != hipSuccess) return NM_OK;
+        } else if (hipEventQuery(ctx->status_event) != hipSuccess) {
+            return NM_OK;          // not there yet: look again next time
+        }
+        ctx->status_pending = false;
+    } else if (!wait) {
+        return NM_OK;              // nothing outstanding that this call could know about
     }
-    ctx->status_pending = false;
+    // (wait without a pending event: the caller has synchronised a graph replay; its copy node has
+    // refreshed the mirror)
     const uint32_t* st = ctx->h_status;
     if (st[NM_ST_LATTICE]) {
         switch (st[NM_ST_LATTICE]) {
@@ -442,7 +451,7 @@ int nm_forest_rows(nm_ctx* ctx, const ForestDev& F, const double* d_feat, int64_
 extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, int64_t n,
                               int64_t feat_stride, double* d_proba, int32_t* d_label, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (!forest || n < 0 || (n > 0 && !d_feat) || (!d_proba && !d_label))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: bad arguments");
     if (!forest->d_packed && (!forest->d_left || !forest->d_right || !forest->d_feature ||
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(256) void k_descriptors(const double* __restrict__ 
 extern "C" int nm_descriptors(nm_ctx* ctx, const double* d_feat, int64_t n, int32_t n_scales,
                               int64_t feat_stride, double* d_out, int64_t out_stride, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (n < 0 || n_scales < 0 || feat_stride < 4 * (int64_t)n_scales ||
         out_stride < 3 * (int64_t)n_scales || (n > 0 && n_scales > 0 && (!d_feat || !d_out)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_descriptors: bad arguments");

@@ -110,6 +110,14 @@ int nm_status_poll(nm_ctx* ctx, bool wait);
 // enqueue a snapshot of the device status words behind the work just enqueued on `s`
 void nm_status_snapshot(nm_ctx* ctx, hipStream_t s);
 
+// is `s` being captured into a hipGraph?  (a step has no host synchronisation and can be captured; while it
+// is, the library must not query events - that would invalidate the capture)
+static inline bool nm_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 // first lines of every entry point that launches work or creates streams / events
 #define NM_ENTER(ctx)                                   \
     if (!(ctx)) return NM_ERR_INVALID;                  \
@@ -117,6 +125,14 @@ void nm_status_snapshot(nm_ctx* ctx, hipStream_t s);
     {                                                   \
         const int _st = nm_status_poll((ctx), false);   \
         if (_st) return _st;                            \
+    }
+// the same for entry points that enqueue on a caller's stream: no event query while it is being captured
+#define NM_ENTER_STREAM(ctx, stream)                                                 \
+    if (!(ctx)) return NM_ERR_INVALID;                                               \
+    nm_device_guard _nm_guard((ctx)->device);                                        \
+    if (!nm_capturing((hipStream_t)(stream))) {                                      \
+        const int _st = nm_status_poll((ctx), false);                                \
+        if (_st) return _st;                                                         \
     }
 
 #define NM_FAIL(ctx, code, ...)                                   \

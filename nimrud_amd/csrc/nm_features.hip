@@ -1583,7 +1583,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
                                  double* d_feat, int64_t feat_stride, int64_t* d_info, void* d_work,
                                  size_t work_bytes, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     int rc = check_scale_args(ctx, "nm_scale_features", d_query, n_query, query_stride, d_search,
                               n_search, search_stride, d_feat, feat_stride, d_work);
     if (rc) return rc;
@@ -1715,7 +1715,7 @@ static void ladder_layout(int64_t nq, int64_t ns, int n_scales, bool shared, boo
     S->order_dev = take(sizeof(OrderDev));
     uint64_t cap = (uint64_t)(ns > 1 ? ns : 1);
     uint64_t hcap = 64;
-    while (hcap < cap * 2) hcap <<= 1;
+    while (hcap < cap * 2 && hcap < (1ull << 31)) hcap <<= 1;      // the mask is 32 bits wide
     S->leaf_capacity = (uint32_t)cap;
     S->hash_capacity = (uint32_t)hcap;
     for (int i = 0; i < n_scales && i < NM_MAX_LADDER; ++i) {
@@ -1889,7 +1889,7 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
                                       int64_t feat_stride, int64_t* d_info, void* d_work,
                                       size_t work_bytes, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (n_scales < 0 || (n_scales > 0 && (!lats || !radii)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_multiscale_features: bad scale arguments");
     if (n_scales == 0) return NM_OK;
@@ -1951,7 +1951,7 @@ extern "C" int nm_ladder_features(nm_ctx* ctx, const double* d_query, int64_t n_
                                   int64_t feat_stride, int64_t* d_info, void* d_work, size_t work_bytes,
                                   void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (n_scales < 0 || (n_scales > 0 && (!edges || !radii)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_ladder_features: bad scale arguments");
     if (n_scales == 0) return NM_OK;
@@ -2062,7 +2062,7 @@ extern "C" int nm_scale_neighbors(nm_ctx* ctx, const double* d_query, int64_t n_
                                   const nm_lattice* lat, double radius, int32_t* d_nbr_count,
                                   const int64_t* d_nbr_offsets, int64_t* d_nbr_index, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (n_query < 0 || m < 0 || query_stride < 3 || (n_query > 0 && !d_query) || (m > 0 && !d_addr))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_scale_neighbors: bad arguments");
     if (!d_nbr_count && !d_nbr_index)
@@ -2139,7 +2139,7 @@ extern "C" int nm_neighborhood_features(nm_ctx* ctx, const double* d_points, con
                                         const double* d_query, int64_t n_neighborhoods,
                                         double* d_feat, int64_t feat_stride, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (n_neighborhoods < 0 || feat_stride < 4 ||
         (n_neighborhoods > 0 && (!d_offsets || !d_query || !d_feat)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_neighborhood_features: bad arguments");

@@ -211,7 +211,7 @@ extern "C" int nm_field_mean(nm_ctx* ctx, const double* d_query, int64_t n_query
                              const nm_lattice* lat, double radius, double* d_out, int64_t out_stride,
                              void* d_work, size_t work_bytes, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (!d_search || n_search < 2 || search_stride < 3 || n_query < 0 || !d_work || !d_attr ||
         dims < 1 || dims > NM_FIELD_MAX_DIMS || attr_stride < dims || out_stride < dims ||
         n_search >= ((int64_t)1 << 31) || (n_query > 0 && (!d_query || !d_out || query_stride < 3)))

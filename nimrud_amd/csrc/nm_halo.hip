@@ -202,7 +202,7 @@ extern "C" int nm_halo_count(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_
                              const double* d_boxes, int32_t n_boxes, int32_t skip, int64_t* d_counts,
                              void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     int rc = check_select(ctx, d_xyz, n, stride, n_boxes);
     if (rc) return rc;
     if (!d_boxes || !d_counts) NM_FAIL(ctx, NM_ERR_INVALID, "nm_halo_count: null arguments");
@@ -214,7 +214,7 @@ extern "C" int nm_halo_pack(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t
                             const double* d_boxes, int32_t n_boxes, int32_t skip,
                             const int64_t* d_offsets, int64_t* d_cursor, double* d_out, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     int rc = check_select(ctx, d_xyz, n, stride, n_boxes);
     if (rc) return rc;
     if (!d_boxes || !d_offsets || !d_cursor || !d_out)
@@ -228,7 +228,7 @@ extern "C" int nm_halo_count_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, 
                                    const uint32_t* d_cellsets, int32_t n_ranks, int32_t skip,
                                    int64_t* d_counts, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     int rc = check_select(ctx, d_xyz, n, stride, n_ranks);
     if (rc) return rc;
     if (!d_global_minmax || !d_cellsets || !d_counts || !(margin > 0.0))
@@ -243,7 +243,7 @@ extern "C" int nm_halo_pack_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, i
                                   const int64_t* d_offsets, int64_t* d_cursor, double* d_out,
                                   void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     int rc = check_select(ctx, d_xyz, n, stride, n_ranks);
     if (rc) return rc;
     if (!d_global_minmax || !d_cellsets || !d_offsets || !d_cursor || !d_out || !(margin > 0.0))
@@ -307,7 +307,7 @@ extern "C" int nm_halo_cellset(nm_ctx* ctx, const double* d_xyz, int64_t n, int6
                                const double* d_global_minmax, double margin, uint32_t* d_cellset,
                                void* d_work, size_t work_bytes, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (n < 0 || stride < 3 || (n > 0 && !d_xyz) || !d_global_minmax || !d_cellset || !d_work ||
         !(margin > 0.0))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_halo_cellset: bad arguments");
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_copy_xyz(const double* __restrict__ xyz
 extern "C" int nm_copy_xyz(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, double* d_out,
                            void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (n < 0 || stride < 3 || (n > 0 && (!d_xyz || !d_out)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_copy_xyz: bad arguments");
     if (n == 0) return NM_OK;
@@ -476,7 +476,7 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
                                 int64_t* h_recv_rows, int64_t* h_sent_rows, double* d_global_minmax,
                                 void* d_work, size_t work_bytes, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     const bool include_self = (mode & NM_HALO_INCLUDE_SELF) != 0;
     mode &= ~NM_HALO_INCLUDE_SELF;
     if (!nccl_comm || n_ranks < 1 || n_ranks > NM_MAX_BOXES || rank < 0 || rank >= n_ranks ||

@@ -87,7 +87,7 @@ __global__ void k_bounds_finish(uint64_t* mm)
 extern "C" int nm_bounds(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
                          double* d_minmax, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (!d_xyz || !d_minmax || n < 1 || stride < 3)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_bounds: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -137,7 +137,7 @@ extern "C" int nm_coordinate_to_address(nm_ctx* ctx, const double* d_xyz, int64_
                                         const nm_lattice* lat, int64_t* d_addr_out, int64_t* d_oob,
                                         void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (n < 0 || stride < 3 || (n > 0 && (!d_xyz || !d_addr_out)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_coordinate_to_address: bad arguments");
     int rc = validate_lattice(ctx, lat);
@@ -284,7 +284,7 @@ extern "C" int nm_voxelize(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t 
                            const nm_lattice* lat, int64_t* d_addr_out, int64_t* d_count,
                            void* d_work, size_t work_bytes, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (!d_xyz || !d_addr_out || !d_count || !d_work || n < 1 || stride < 3 ||
         n >= (int64_t)1 << 31)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_voxelize: bad arguments");
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void k_addr_to_coord(const int64_t* __restrict
 extern "C" int nm_address_to_coordinate(nm_ctx* ctx, const int64_t* d_addr, int64_t m,
                                         const nm_lattice* lat, double* d_xyz_out, void* stream)
 {
-    NM_ENTER(ctx);
+    NM_ENTER_STREAM(ctx, stream);
     if (m < 0 || (m > 0 && (!d_addr || !d_xyz_out)))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_address_to_coordinate: bad arguments");
     int rc = validate_lattice(ctx, lat);
@@ -1002,7 +1002,7 @@ __device__ inline void nm_scale_finish(ScaleDev* S, double radius, uint32_t hash
     if (cap > leaf_capacity) cap = leaf_capacity;
     if (cap < 1) cap = 1;
     uint64_t hcap = 64;
-    while (hcap < cap * 2 && hcap < hash_capacity) hcap <<= 1;
+    while (hcap < cap * 2 && hcap < hash_capacity && hcap < (1ull << 31)) hcap <<= 1;
     S->I.hash_mask = (uint32_t)(hcap - 1);
     S->I.leaf_capacity = (uint32_t)cap;
     S->r2 = radius * radius;
