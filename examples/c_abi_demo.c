@@ -4,8 +4,10 @@
  * what a compiled host would do to replace nimrud/minimal/multiscale.py:27-67 (process_single_core) with
  * libnimrud_hip.so: device buffers from hipMalloc, the cloud's extrema from nm_bounds, the lattices of
  * VoxelFilter.__init__ (nimrud/utils/geometry.py:37-38, 55-64) built on the host, one nm_multiscale_features
- * call for the whole ladder.  tests/test_gpu_parity.py runs it and compares its output with the oracle and
- * with the Python host's.
+ * call for the whole ladder - or, with NM_DEMO_DEVICE_LATTICE=1 in the environment, no lattice code at all:
+ * nm_ladder_features measures the cloud and builds the lattices on the device, and nm_check reports what
+ * VoxelFilter would have raised.  tests/test_gpu_parity.py runs both forms and compares their output with the
+ * oracle and with the Python host's.
  *
  *   c_abi_demo <points.f64> <n> <features_out.f64> <edge> <radius> [<edge> <radius> ...]
  *
@@ -86,28 +88,43 @@ int main(int argc, char** argv)
     CHECK_HIP(hipMalloc((void**)&d_feat, (size_t)n * 4 * n_scales * sizeof(double)));
     CHECK_HIP(hipMemcpyAsync(d_xyz, h_xyz, (size_t)n * 24, hipMemcpyHostToDevice, stream));
 
-    /* the cloud's extrema (points.min(0) / points.max(0), geometry.py:37-38) */
-    double mm[6];
-    CHECK_NM(nm_bounds(ctx, d_xyz, n, 3, d_minmax, stream));
-    CHECK_HIP(hipMemcpyAsync(mm, d_minmax, sizeof(mm), hipMemcpyDeviceToHost, stream));
-    CHECK_HIP(hipStreamSynchronize(stream));
-
     nm_lattice* lats = (nm_lattice*)calloc((size_t)n_scales, sizeof(nm_lattice));
     double* radii = (double*)calloc((size_t)n_scales, sizeof(double));
+    double* edges = (double*)calloc((size_t)n_scales, sizeof(double));
     for (int s = 0; s < n_scales; ++s) {
-        const double e = atof(argv[4 + 2 * s]);
+        edges[s] = atof(argv[4 + 2 * s]);
         radii[s] = atof(argv[5 + 2 * s]);
-        if (make_lattice(mm, mm + 3, e, &lats[s]) != 0) {
-            fprintf(stderr, "edge length %g cannot address this space\n", e);
-            return 1;
-        }
     }
-    const size_t work_bytes = nm_multiscale_workspace_bytes(n, n, lats, n_scales);
+    const char* mode = getenv("NM_DEMO_DEVICE_LATTICE");
+    const int device_lattice = mode && mode[0] == '1';
+    size_t work_bytes;
     void* d_work;
-    CHECK_HIP(hipMalloc(&d_work, work_bytes));
-    /* query cloud = search cloud: same pointer, same stride */
-    CHECK_NM(nm_multiscale_features(ctx, d_xyz, n, 3, d_xyz, n, 3, lats, radii, n_scales, d_feat,
+    if (device_lattice) {
+        /* everything on the device: no extrema, no lattices on the host, nothing to wait for */
+        work_bytes = nm_ladder_workspace_bytes(n, n, n_scales);
+        CHECK_HIP(hipMalloc(&d_work, work_bytes));
+        CHECK_NM(nm_ladder_features(ctx, d_xyz, n, 3, d_xyz, n, 3, edges, radii, n_scales, NULL, d_feat,
                                     4 * (int64_t)n_scales, NULL, d_work, work_bytes, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        CHECK_NM(nm_check(ctx, 1));      /* e.g. "edge length is too small to address this space" */
+    } else {
+        /* the cloud's extrema (points.min(0) / points.max(0), geometry.py:37-38) */
+        double mm[6];
+        CHECK_NM(nm_bounds(ctx, d_xyz, n, 3, d_minmax, stream));
+        CHECK_HIP(hipMemcpyAsync(mm, d_minmax, sizeof(mm), hipMemcpyDeviceToHost, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        for (int s = 0; s < n_scales; ++s) {
+            if (make_lattice(mm, mm + 3, edges[s], &lats[s]) != 0) {
+                fprintf(stderr, "edge length %g cannot address this space\n", edges[s]);
+                return 1;
+            }
+        }
+        work_bytes = nm_multiscale_workspace_bytes(n, n, lats, n_scales);
+        CHECK_HIP(hipMalloc(&d_work, work_bytes));
+        /* query cloud = search cloud: same pointer, same stride */
+        CHECK_NM(nm_multiscale_features(ctx, d_xyz, n, 3, d_xyz, n, 3, lats, radii, n_scales, d_feat,
+                                        4 * (int64_t)n_scales, NULL, d_work, work_bytes, stream));
+    }
     double* h_feat = (double*)malloc((size_t)n * 4 * n_scales * sizeof(double));
     CHECK_HIP(hipMemcpyAsync(h_feat, d_feat, (size_t)n * 4 * n_scales * sizeof(double),
                              hipMemcpyDeviceToHost, stream));
@@ -118,8 +135,8 @@ int main(int argc, char** argv)
         return 1;
     }
     fclose(f);
-    printf("%lld points, %d scales, workspace %.1f MB, abi %d\n", (long long)n, n_scales,
-           work_bytes / 1e6, nm_abi_version());
+    printf("%lld points, %d scales, workspace %.1f MB, abi %d, lattices built on the %s\n", (long long)n,
+           n_scales, work_bytes / 1e6, nm_abi_version(), device_lattice ? "device" : "host");
     (void)hipFree(d_work);
     (void)hipFree(d_feat);
     (void)hipFree(d_minmax);
@@ -128,6 +145,7 @@ int main(int argc, char** argv)
     nm_destroy(ctx);
     free(h_feat);
     free(radii);
+    free(edges);
     free(lats);
     free(h_xyz);
     return 0;

@@ -765,12 +765,20 @@ def test_plain_c_host_through_the_c_abi(tmp_path):
     args = [exe, str(src), str(len(pts)), str(dst)]
     for e, r in zip(edges, radii):
         args += [repr(e), repr(r)]
-    done = subprocess.run(args, capture_output=True, text=True, timeout=120)
-    assert done.returncode == 0, done.stderr
-    got = np.fromfile(dst, dtype="<f8").reshape(len(pts), 4 * len(edges))
     via_python = multiscale.process_single_core(pts, pts, edges, radii)
-    assert np.array_equal(got, via_python)
-    assert_features_close(got, oracle.process_c(pts, pts, edges, radii), pts)
+    want = oracle.process_c(pts, pts, edges, radii)
+    for device_lattice in ("0", "1"):      # lattices built in C from nm_bounds / on the device by the library
+        env = dict(os.environ, NM_DEMO_DEVICE_LATTICE=device_lattice)
+        done = subprocess.run(args, capture_output=True, text=True, timeout=120, env=env)
+        assert done.returncode == 0, done.stderr
+        assert ("device" if device_lattice == "1" else "host") in done.stdout
+        got = np.fromfile(dst, dtype="<f8").reshape(len(pts), 4 * len(edges))
+        assert np.array_equal(got, via_python)
+        assert_features_close(got, want, pts)
+    # what VoxelFilter raises on the host comes back through nm_check
+    bad = subprocess.run([exe, str(src), str(len(pts)), str(dst), "1e-9", "3e-9"], capture_output=True,
+                         text=True, timeout=120, env=dict(os.environ, NM_DEMO_DEVICE_LATTICE="1"))
+    assert bad.returncode == 3 and "too small" in bad.stderr
 
 
 # ---- edge cases --------------------------------------------------------------------------------------
