@@ -218,9 +218,12 @@ struct HashEntry {
     uint32_t pad;
 };
 
-// the occupancy index of one scale (all pointers into the caller's workspace)
+// the occupancy index of one scale (all pointers into the caller's workspace).
+// DENSE form (hash == nullptr): the lattice has so few superblocks (coarse scales: a few hundred to 2^18) that
+// every one of them gets a leaf, leaf number = superblock key - no table, no probing, nothing to insert or to
+// wait for; hash_mask = number of superblocks - 1.
 struct IndexDev {
-    struct HashEntry* hash;  // open-addressing table: one 16-byte entry per slot, key + leaf number
+    struct HashEntry* hash;  // open-addressing table: one 16-byte entry per slot, key + leaf number; or null
     uint32_t hash_mask;      // capacity - 1 (capacity is a power of two)
     uint32_t* leaf;          // leaves, NM_LEAF_WORDS words each
     uint32_t leaf_capacity;  // leaves the workspace has room for
@@ -255,6 +258,7 @@ struct OrderDev {
 };
 
 constexpr int NM_MAX_LADDER = 32;     // scales per ladder call
+constexpr int NM_DENSE_LOG2 = 18;     // a scale with at most 2^18 superblocks (64 MB of leaves) is indexed densely
 
 #if defined(__HIPCC__)
 
@@ -309,6 +313,7 @@ __device__ __forceinline__ uint32_t nm_hash64(uint64_t k)
 // leaf number of a superblock, or -1
 __device__ __forceinline__ int32_t nm_hash_find(const IndexDev& I, uint64_t key)
 {
+    if (!I.hash) return key <= (uint64_t)I.hash_mask ? (int32_t)key : -1;      // dense: leaf = superblock
     uint32_t slot = nm_hash64(key) & I.hash_mask;
     for (;;) {
         const uint4 e = *(const uint4*)&I.hash[slot];          // one 16-byte load: key and value

@@ -1198,7 +1198,7 @@ __global__ void k_publish_info_all(const ScaleDev* __restrict__ ladder, int32_t 
         info[4 * i + 0] = bad ? -1 : (int64_t)counters[1];
         info[4 * i + 1] = counters[8];   // neighborhoods with population < 2
         info[4 * i + 2] = counters[9];   // extra passes of the search kernel
-        info[4 * i + 3] = counters[0];   // leaves
+        info[4 * i + 3] = ladder[i].I.hash ? counters[0] : counters[4];   // leaves that hold a voxel
     }
 }
 
@@ -1621,7 +1621,7 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
                         s);
     if (rc) return rc;
     ScaleDev* d_scale = (ScaleDev*)(w + S.scale_dev);
-    rc = nm_ladder_put(ctx, &L, &I, &radius, 1, -1, d_scale, nullptr, s);
+    rc = nm_ladder_put(ctx, &L, &I, &radius, 1, -1, 0u, d_scale, nullptr, s);
     if (rc) return rc;
 
     const uint32_t* order = (const uint32_t*)(w + S.val_sorted);
@@ -1931,7 +1931,7 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         I[i].leaf_capacity = lay.leaf_capacity;
         I[i].status = ctx->d_status;
     }
-    rc = nm_ladder_put(ctx, L, I, radii, n_scales, finest, (ScaleDev*)(w + S.ladder),
+    rc = nm_ladder_put(ctx, L, I, radii, n_scales, finest, S.leaf_capacity, (ScaleDev*)(w + S.ladder),
                        (OrderDev*)(w + S.order_dev), s);
     if (rc) return rc;
     const LatticeDev& Lf = L[finest];

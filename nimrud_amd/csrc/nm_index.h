@@ -29,8 +29,10 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
                    size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
 
 // the device-resident scale array: from host lattices, or from the cloud's extrema on the device
+// leaf_alloc: leaves the workspace has room for per scale (> 0: coarse scales may be indexed densely);
+// 0: keep every index exactly as the host sized it (the one-scale path)
 int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const double* radii, int n_scales,
-                  int finest, ScaleDev* d_ladder, OrderDev* d_order, hipStream_t s);
+                  int finest, uint32_t leaf_alloc, ScaleDev* d_ladder, OrderDev* d_order, hipStream_t s);
 int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const double* edges, const double* radii,
                    int n_scales, int finest, void* const* hash, void* const* leaf, void* const* counters,
                    uint32_t hash_capacity, uint32_t leaf_capacity, ScaleDev* d_ladder, OrderDev* d_order,

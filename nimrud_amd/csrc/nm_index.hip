@@ -649,6 +649,7 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
         if (!ladder[sc].valid) continue;
         const LatticeDev L = ladder[sc].L;
         const IndexDev I = ladder[sc].I;
+        const bool dense = I.hash == nullptr;      // leaf = superblock key: no table, nothing to insert
         __syncthreads();       // the previous scale's flush has read the scratch
         if (threadIdx.x == 0) won_count = 0u;
         __syncthreads();
@@ -682,8 +683,9 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
             }
     #pragma unroll
             for (int g = 0; g < FUSED_GROUPS; ++g) {
-                slot[g] = nm_hash64(sb[g]) & I.hash_mask;
-                peek[g] = head[g] ? I.hash[slot[g]].key : sb[g];
+                // dense index: the "slot" of a superblock is its key, which also is its leaf; nothing to probe
+                slot[g] = dense ? (uint32_t)sb[g] : nm_hash64(sb[g]) & I.hash_mask;
+                peek[g] = (head[g] && !dense) ? I.hash[slot[g]].key : sb[g];
             }
     #pragma unroll
             for (int g = 0; g < FUSED_GROUPS; ++g) {
@@ -776,14 +778,15 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
                 row_head[g] = sb_head[g] || (loc[g] >> NM_SBX_BITS) != (prev_loc >> NM_SBX_BITS);
                 val[g] = LEAF_NONE;
                 if (sb_head[g] && valid[g])
-                    val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                    val[g] = dense ? sl[g]
+                                   : __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
             }
     #pragma unroll
             for (int g = 0; g < FUSED_GROUPS; ++g) {
                 if (sb_head[g] && valid[g]) {
-                    // not published yet: its creator is still in phase 1
-                    for (int spin = 0; val[g] == LEAF_PENDING && spin < NM_SPIN_LIMIT; ++spin) {
+                    // not published yet: its creator is still in phase 1.  (a dense index has no creators)
+                    for (int spin = 0; !dense && val[g] == LEAF_PENDING && spin < NM_SPIN_LIMIT; ++spin) {
                         __builtin_amdgcn_s_sleep(8);
                         val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -993,18 +996,28 @@ struct LadderSpec {
 };
 
 __device__ inline void nm_scale_finish(ScaleDev* S, double radius, uint32_t hash_capacity,
-                                       uint32_t leaf_capacity)
+                                       uint32_t leaf_capacity, bool allow_dense)
 {
     const LatticeDev& L = S->L;
+    const int sb_bits = L.bx + L.by + L.bz;
+    if (allow_dense && sb_bits <= NM_DENSE_LOG2 && (1ull << sb_bits) <= (uint64_t)leaf_capacity) {
+        // few superblocks (the coarse scales): one leaf each, no directory
+        S->I.hash = nullptr;
+        S->I.hash_mask = (1u << sb_bits) - 1u;
+        S->I.leaf_capacity = 1u << sb_bits;
+        leaf_capacity = 0;          // skip the sizing below
+    }
     // as many leaves as the lattice has superblocks or the cloud has points, whichever is smaller; the
     // table is kept at most half full
-    uint64_t cap = 1ull << (L.bx + L.by + L.bz);
-    if (cap > leaf_capacity) cap = leaf_capacity;
-    if (cap < 1) cap = 1;
-    uint64_t hcap = 64;
-    while (hcap < cap * 2 && hcap < hash_capacity && hcap < (1ull << 31)) hcap <<= 1;
-    S->I.hash_mask = (uint32_t)(hcap - 1);
-    S->I.leaf_capacity = (uint32_t)cap;
+    if (S->I.hash) {
+        uint64_t cap = 1ull << sb_bits;
+        if (cap > leaf_capacity) cap = leaf_capacity;
+        if (cap < 1) cap = 1;
+        uint64_t hcap = 64;
+        while (hcap < cap * 2 && hcap < hash_capacity && hcap < (1ull << 31)) hcap <<= 1;
+        S->I.hash_mask = (uint32_t)(hcap - 1);
+        S->I.leaf_capacity = (uint32_t)cap;
+    }
     S->r2 = radius * radius;
     // static pruning of the candidate window is sound only while the rounding of cells and centres stays
     // far below the 1e-4-cell padding of the bounds: 16 ulp of the largest coordinate the lattice can
@@ -1066,7 +1079,7 @@ __global__ void k_make_ladder(const double* __restrict__ minmax, LadderSpec P, S
         S.I.counters = P.counters[sc];
         S.I.status = status;
         S.valid = bad ? 0 : 1;
-        nm_scale_finish(&S, P.radius[sc], P.hash_capacity, P.leaf_capacity);
+        nm_scale_finish(&S, P.radius[sc], P.hash_capacity, P.leaf_capacity, !bad);
         ladder[sc] = S;
         if (sc == P.finest) {
             OrderDev O;
@@ -1079,12 +1092,13 @@ __global__ void k_make_ladder(const double* __restrict__ minmax, LadderSpec P, S
 
 // the same array from lattices the host already has (nm_multiscale_features, nm_scale_features)
 struct LadderPut {
+    int32_t allow_dense;               // the ladder path may index coarse scales densely; nm_scale_features not
     int32_t n_scales;
     int32_t first;                     // index of P.scale[0] in the device array
     int32_t finest;                    // index (in the device array) of the ordering scale, -1: not here
     ScaleDev scale[8];
     double radius[8];
-    uint32_t hash_capacity[8], leaf_capacity[8];
+    uint32_t hash_capacity[8], leaf_alloc[8];      // slots of the table, leaves the workspace has room for
 };
 
 __global__ void k_put_ladder(LadderPut P, ScaleDev* __restrict__ ladder, OrderDev* __restrict__ order_dev)
@@ -1094,10 +1108,12 @@ __global__ void k_put_ladder(LadderPut P, ScaleDev* __restrict__ ladder, OrderDe
         ScaleDev S = P.scale[t];
         S.valid = 1;
         const uint32_t hmask = S.I.hash_mask, lcap = S.I.leaf_capacity;
-        nm_scale_finish(&S, P.radius[t], P.hash_capacity[t], P.leaf_capacity[t]);
-        // the host sized this index exactly: keep its numbers
-        S.I.hash_mask = hmask;
-        S.I.leaf_capacity = lcap;
+        nm_scale_finish(&S, P.radius[t], P.hash_capacity[t], P.leaf_alloc[t], P.allow_dense != 0);
+        if (S.I.hash) {
+            // the host sized this index exactly: keep its numbers
+            S.I.hash_mask = hmask;
+            S.I.leaf_capacity = lcap;
+        }
         ladder[P.first + t] = S;
         if (order_dev && P.first + t == P.finest) {
             OrderDev O;
@@ -1108,10 +1124,11 @@ __global__ void k_put_ladder(LadderPut P, ScaleDev* __restrict__ ladder, OrderDe
 }
 
 int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const double* radii, int n_scales,
-                  int finest, ScaleDev* d_ladder, OrderDev* d_order, hipStream_t s)
+                  int finest, uint32_t leaf_alloc, ScaleDev* d_ladder, OrderDev* d_order, hipStream_t s)
 {
     for (int first = 0; first < n_scales; first += 8) {
         LadderPut P;
+        P.allow_dense = leaf_alloc > 0;
         P.n_scales = n_scales - first < 8 ? n_scales - first : 8;
         P.first = first;
         P.finest = finest;
@@ -1123,7 +1140,7 @@ int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const dou
             P.scale[t].prune_ok = 0;
             P.radius[t] = radii[first + t];
             P.hash_capacity[t] = I[first + t].hash_mask + 1u;
-            P.leaf_capacity[t] = I[first + t].leaf_capacity;
+            P.leaf_alloc[t] = leaf_alloc ? leaf_alloc : I[first + t].leaf_capacity;
         }
         k_put_ladder<<<1, 64, 0, s>>>(P, d_ladder, d_order);
     }
@@ -1176,6 +1193,14 @@ __global__ __launch_bounds__(256) void k_index_clear_all(const ScaleDev* __restr
     const IndexDev I = ladder[blockIdx.y].I;
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if (!I.hash) {
+        // dense: every superblock's leaf, zeroed; all of them count as allocated
+        uint4* l = (uint4*)I.leaf;
+        const uint64_t quads = ((uint64_t)I.hash_mask + 1ull) * (NM_LEAF_WORDS / 4);
+        for (uint64_t i = tid; i < quads; i += stride) l[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 64) I.counters[tid] = tid == 0 ? I.hash_mask + 1u : 0u;
+        return;
+    }
     uint4* h = (uint4*)I.hash;
     const uint64_t slots = (uint64_t)I.hash_mask + 1ull;
     for (uint64_t i = tid; i < slots; i += stride)
@@ -1203,6 +1228,21 @@ __global__ __launch_bounds__(256) void k_count_voxels_all(const ScaleDev* __rest
     if (threadIdx.x == 0) {
         const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         if (t) atomicAdd(&I.counters[1], t);
+    }
+    if (!I.hash) {
+        // dense index: every superblock has a leaf; the leaves that hold a voxel are counted for the info
+        // block (counters[4]), so that "leaves" means the same thing in both forms
+        uint32_t occupied = 0;
+        for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < n_leaves; l += gridDim.x * blockDim.x) {
+            const uint4* q = (const uint4*)(I.leaf + (size_t)l * NM_LEAF_WORDS);
+            uint32_t any = 0;
+#pragma unroll
+            for (int i = 0; i < NM_LEAF_WORDS / 4; ++i) any |= q[i].x | q[i].y | q[i].z | q[i].w;
+            occupied += any ? 1u : 0u;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) occupied += __shfl_xor(occupied, off);
+        if ((threadIdx.x & 63) == 0 && occupied) atomicAdd(&I.counters[4], occupied);
     }
 }
 
