@@ -651,11 +651,81 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
         const IndexDev I = ladder[sc].I;
         const bool dense = I.hash == nullptr;      // leaf = superblock key: no table, nothing to insert
         __syncthreads();       // the previous scale's flush has read the scratch
-        if (threadIdx.x == 0) won_count = 0u;
-        __syncthreads();
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         const int64_t wave_lo = (int64_t)blockIdx.x * FUSED_CHUNK + (int64_t)w * FUSED_WAVE_KEYS;
         const unsigned long long below = (2ull << lane) - 1ull;
+        if (dense) {
+            // ---- dense index: one phase.  cell key -> (row word of the superblock's own leaf, bit); runs of
+            //      equal row word are OR-ed inside the wave, the block's distinct words meet in the LDS table
+            //      and leave as one atomicOr each.  nothing to insert, nothing to wait for.
+            for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
+                t_word[t] = BITS_EMPTY;
+                t_bits[t] = 0u;
+            }
+            __syncthreads();
+#ifdef NM_DIAG_FORCE_TIMEOUT
+            // diagnostic build (tests only): behave as if the hash form's bounded wait had run out
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                I.counters[3] = 1u;
+                I.status[NM_ST_INDEX_TIMEOUT] = 1u;
+            }
+#endif
+            for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {
+                const int64_t base = wave_lo + (int64_t)it * 64;
+                if (base >= n) break;
+                uint32_t word[FUSED_GROUPS], bits[FUSED_GROUPS];
+                bool valid[FUSED_GROUPS];
+#pragma unroll
+                for (int g = 0; g < FUSED_GROUPS; ++g) {
+                    const int64_t i = base + g * 64 + lane;
+                    valid[g] = i < n;
+                    word[g] = BITS_EMPTY;
+                    bits[g] = 0u;
+                    if (valid[g]) {
+                        const uint64_t k = nm_point_key(xyz + i * 3, L);
+                        word[g] = (uint32_t)(k >> NM_SBX_BITS);      // superblock * 64 + row inside it
+                        bits[g] = 1u << ((uint32_t)k & 31u);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < FUSED_GROUPS; ++g) {
+                    const uint32_t prev = __shfl_up(word[g], 1);
+                    const bool row_head = lane == 0 || word[g] != prev;
+                    const unsigned long long rowm = __ballot(row_head);
+                    const int seg_start = 63 - __clzll((long long)(rowm & below));
+                    uint32_t b = bits[g];
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t other = __shfl_up(b, off);
+                        if (lane - off >= seg_start) b |= other;
+                    }
+                    const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull));
+                    if (tail) {
+                        uint32_t ts = (word[g] * 0x9E3779B1u) >> (32 - FUSED_TABLE_BITS);
+                        bool stored = false;
+#pragma unroll 1
+                        for (int probe = 0; probe < 8; ++probe) {
+                            const uint32_t seen = atomicCAS(&t_word[ts], BITS_EMPTY, word[g]);
+                            if (seen == BITS_EMPTY || seen == word[g]) {
+                                atomicOr(&t_bits[ts], b);
+                                stored = true;
+                                break;
+                            }
+                            ts = (ts + 1) & (FUSED_TABLE - 1);
+                        }
+                        if (!stored) atomicOr(&I.leaf[word[g]], b);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
+                const uint32_t wd = t_word[t];
+                if (wd != BITS_EMPTY) atomicOr(&I.leaf[wd], t_bits[t]);
+            }
+            continue;
+        }
+        if (threadIdx.x == 0) won_count = 0u;
+        __syncthreads();
 
         // ---- phase 1: keys, run heads into the table, every point's (slot, local) into the stash
         uint64_t carry = ~0ull;          // superblock of the previous point of this wave; none at its start:
