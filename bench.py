@@ -335,8 +335,12 @@ def main():
         features_only_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     # occupied voxels per scale (for the algorithmic byte count), outside the timed region
-    _, info = multiscale.process_gpu(cloud, cloud, edges, radii, return_info=True) \
-        if world == 1 else (None, plan.last_info())
+    if world == 1:
+        _, info = multiscale.process_gpu(cloud, cloud, edges, radii, return_info=True)
+    else:
+        plan.want_info = True
+        parallel.process_tile(plan)
+        info = plan.last_info()
     voxels = [i.voxels for i in info]
     extra_passes = [i.extra_passes for i in info]
     n_local_search = cloud.shape[0] if world == 1 else plan.search_points()

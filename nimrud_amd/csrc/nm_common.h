@@ -219,7 +219,7 @@ struct HashEntry {
 };
 
 // the occupancy index of one scale (all pointers into the caller's workspace).
-// DENSE form (hash == nullptr): the lattice has so few superblocks (coarse scales: a few hundred to 2^18) that
+// DENSE form (hash == nullptr): the lattice has so few superblocks (at most 2^21 and no more than points) that
 // every one of them gets a leaf, leaf number = superblock key - no table, no probing, nothing to insert or to
 // wait for; hash_mask = number of superblocks - 1.
 struct IndexDev {
@@ -258,7 +258,10 @@ struct OrderDev {
 };
 
 constexpr int NM_MAX_LADDER = 32;     // scales per ladder call
-constexpr int NM_DENSE_LOG2 = 18;     // a scale with at most 2^18 superblocks (64 MB of leaves) is indexed densely
+#ifndef NM_DENSE_LOG2_VALUE
+#define NM_DENSE_LOG2_VALUE 21
+#endif
+constexpr int NM_DENSE_LOG2 = NM_DENSE_LOG2_VALUE;     // a scale with at most 2^21 superblocks (and no more than there are points) is indexed densely: up to 512 MB of leaves, zeroed per call at HBM speed - cheaper than the insert protocol (measured at 2^18 and 2^21)
 
 #if defined(__HIPCC__)
 

@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(256) void k_count_voxels_all(const ScaleDev* __rest
 
 int nm_index_clear_all(nm_ctx* ctx, const ScaleDev* d_ladder, int n, hipStream_t s)
 {
-    k_index_clear_all<<<dim3(256, n), 256, 0, s>>>(d_ladder);
+    k_index_clear_all<<<dim3(1024, n), 256, 0, s>>>(d_ladder);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }

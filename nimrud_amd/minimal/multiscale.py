@@ -144,7 +144,10 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
         # 8-byte stores outside the allocation
         raise ValueError("out must be a (Nq, >= 4*S) fp64 tensor on the clouds' device with unit column "
                          "stride")
-    info = torch.zeros((max(n_scales, 1), 4), dtype=torch.int64, device=rt.device)
+    # the per-scale counters (voxels, degenerate neighborhoods, extra passes, leaves) cost a pass over the
+    # index: only when somebody will look at them
+    want_info = bool(strict or return_info or verbose)
+    info = torch.zeros((max(n_scales, 1), 4), dtype=torch.int64, device=rt.device) if want_info else None
     if n_scales == 0:
         return (out, []) if return_info else out
 
@@ -186,7 +189,7 @@ def process_gpu(query_cloud, search_cloud, edge_lengths, radii, verbose=False, s
             inner_start = time.perf_counter()
             covariance_columns(s)
             _scale_into(rt, query, search, shared, lo, hi, this_edge, this_radius,
-                        out[:, 4 * s:4 * s + 4], info[s])
+                        out[:, 4 * s:4 * s + 4], info[s] if info is not None else None)
             _report_scale(rt, verbose, nq, info, s, this_edge, this_radius, inner_start)
     finally:
         if cov_out is not None:

@@ -214,6 +214,7 @@ class TilePlan(object):
                                   and dist.get_backend(group) == "gloo"
                                   and isinstance(cloud, torch.Tensor) and cloud.is_cuda)
         self._info = None
+        self.want_info = False          # per-scale counters (a pass over the index): only on request
         self._search_points = cloud.shape[0]
         self.halo_sent = 0
         self.halo_received = 0
@@ -234,7 +235,10 @@ class TilePlan(object):
         self.backend.copy_xyz(self.cloud, self._buffer[:n])
 
     def last_info(self):
+        """ScaleInfo per scale of the last process_tile call made with plan.want_info = True"""
         from nimrud_amd.minimal.multiscale import ScaleInfo
+        if self._info is None:
+            raise RuntimeError("set plan.want_info = True before the process_tile call to be inspected")
         host = self._info.cpu().numpy()
         return [ScaleInfo(row) for row in host[:len(self.edge_lengths)]]
 
@@ -345,7 +349,8 @@ def process_tile(plan, out=None):
     plan._search_points = search.shape[0]
     if out is None:
         out = torch.empty((n, 4 * n_scales), dtype=torch.float64, device=cloud.device)
-    info = torch.zeros((max(n_scales, 1), 4), dtype=torch.int64, device=cloud.device)
+    info = torch.zeros((max(n_scales, 1), 4), dtype=torch.int64, device=cloud.device) \
+        if plan.want_info else None
     be.features(search, n, bounds, plan.edge_lengths, plan.radii, out, info)
     plan._info = info
     return out
