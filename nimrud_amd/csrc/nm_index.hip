@@ -614,7 +614,7 @@ constexpr uint32_t LEAF_NONE = 0xFFFFFFFEu;        // published: no room (capaci
 // budget (6 waves per SIMD), not LDS, bounds the occupancy; the kernel is a chain of dependent
 // memory operations and lives on the number of waves in flight.
 #ifndef NM_FUSED_ITERS
-#define NM_FUSED_ITERS 8
+#define NM_FUSED_ITERS 4      // = groups: a wave reads its 256 points once for all densely indexed scales
 #endif
 #ifndef NM_FUSED_GROUPS
 #define NM_FUSED_GROUPS 4
@@ -641,59 +641,66 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
     uint32_t* won_slot = scratch;
     uint32_t* t_word = scratch;
     uint32_t* t_bits = scratch + FUSED_TABLE;
-    // one launch builds every index of the ladder: the block keeps its 2048 points and walks the scales,
-    // so the coordinates of the coarser scales come out of the cache the finest one filled, and the
+    // one launch builds every index of the ladder: the block keeps its points and walks the scales; the
     // launch has one ramp and one tail instead of one per scale
-#pragma nounroll
-    for (int32_t sc = 0; sc < n_scales; ++sc) {
-        if (!ladder[sc].valid) continue;
-        const LatticeDev L = ladder[sc].L;
-        const IndexDev I = ladder[sc].I;
-        const bool dense = I.hash == nullptr;      // leaf = superblock key: no table, nothing to insert
-        __syncthreads();       // the previous scale's flush has read the scratch
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const int64_t wave_lo = (int64_t)blockIdx.x * FUSED_CHUNK + (int64_t)w * FUSED_WAVE_KEYS;
-        const unsigned long long below = (2ull << lane) - 1ull;
-        if (dense) {
-            // ---- dense index: one phase.  cell key -> (row word of the superblock's own leaf, bit); runs of
-            //      equal row word are OR-ed inside the wave, the block's distinct words meet in the LDS table
-            //      and leave as one atomicOr each.  nothing to insert, nothing to wait for.
-            for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
-                t_word[t] = BITS_EMPTY;
-                t_bits[t] = 0u;
-            }
-            __syncthreads();
-#ifdef NM_DIAG_FORCE_TIMEOUT
-            // diagnostic build (tests only): behave as if the hash form's bounded wait had run out
-            if (blockIdx.x == 0 && threadIdx.x == 0) {
-                I.counters[3] = 1u;
-                I.status[NM_ST_INDEX_TIMEOUT] = 1u;
-            }
-#endif
-            for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {
-                const int64_t base = wave_lo + (int64_t)it * 64;
-                if (base >= n) break;
-                uint32_t word[FUSED_GROUPS], bits[FUSED_GROUPS];
-                bool valid[FUSED_GROUPS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave_lo = (int64_t)blockIdx.x * FUSED_CHUNK + (int64_t)w * FUSED_WAVE_KEYS;
+    const unsigned long long below = (2ull << lane) - 1ull;
+
+    // ---- pass 1: the densely indexed scales (leaf = superblock key: no table, nothing to insert, nothing to
+    //      wait for).  the wave's points are read ONCE into registers and serve every dense scale: cell key ->
+    //      (row word of the superblock's own leaf, bit); runs of equal row word are OR-ed inside the wave, the
+    //      block's distinct words meet in the LDS table and leave as one atomicOr each.
+    bool any_dense = false;
+    for (int32_t sc = 0; sc < n_scales; ++sc)
+        any_dense = any_dense || (ladder[sc].valid && ladder[sc].I.hash == nullptr);
+    if (any_dense) {
+        for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {      // (trip count is block-uniform: barriers)
+            const int64_t base = wave_lo + (int64_t)it * 64;
+            double px[FUSED_GROUPS], py[FUSED_GROUPS], pz[FUSED_GROUPS];
+            bool valid[FUSED_GROUPS];
 #pragma unroll
-                for (int g = 0; g < FUSED_GROUPS; ++g) {
-                    const int64_t i = base + g * 64 + lane;
-                    valid[g] = i < n;
-                    word[g] = BITS_EMPTY;
-                    bits[g] = 0u;
-                    if (valid[g]) {
-                        const uint64_t k = nm_point_key(xyz + i * 3, L);
-                        word[g] = (uint32_t)(k >> NM_SBX_BITS);      // superblock * 64 + row inside it
-                        bits[g] = 1u << ((uint32_t)k & 31u);
-                    }
+            for (int g = 0; g < FUSED_GROUPS; ++g) {
+                const int64_t i = base + g * 64 + lane;
+                valid[g] = i < n;
+                px[g] = py[g] = pz[g] = 0.0;
+                if (valid[g]) {
+                    px[g] = xyz[i * 3 + 0];
+                    py[g] = xyz[i * 3 + 1];
+                    pz[g] = xyz[i * 3 + 2];
                 }
+            }
+#pragma nounroll
+            for (int32_t sc = 0; sc < n_scales; ++sc) {
+                if (!ladder[sc].valid || ladder[sc].I.hash != nullptr) continue;
+                const LatticeDev L = ladder[sc].L;
+                const IndexDev I = ladder[sc].I;
+                __syncthreads();       // the previous flush has read the table
+                for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
+                    t_word[t] = BITS_EMPTY;
+                    t_bits[t] = 0u;
+                }
+                __syncthreads();
+#ifdef NM_DIAG_FORCE_TIMEOUT
+                // diagnostic build (tests only): behave as if the hash form's bounded wait had run out
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    I.counters[3] = 1u;
+                    I.status[NM_ST_INDEX_TIMEOUT] = 1u;
+                }
+#endif
 #pragma unroll
                 for (int g = 0; g < FUSED_GROUPS; ++g) {
-                    const uint32_t prev = __shfl_up(word[g], 1);
-                    const bool row_head = lane == 0 || word[g] != prev;
+                    uint32_t word = BITS_EMPTY, b = 0u;
+                    if (valid[g]) {
+                        const double p[3] = {px[g], py[g], pz[g]};
+                        const uint64_t k = nm_point_key(p, L);
+                        word = (uint32_t)(k >> NM_SBX_BITS);      // superblock * 64 + row inside it
+                        b = 1u << ((uint32_t)k & 31u);
+                    }
+                    const uint32_t prev = __shfl_up(word, 1);
+                    const bool row_head = lane == 0 || word != prev;
                     const unsigned long long rowm = __ballot(row_head);
                     const int seg_start = 63 - __clzll((long long)(rowm & below));
-                    uint32_t b = bits[g];
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) {
                         const uint32_t other = __shfl_up(b, off);
@@ -701,29 +708,39 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
                     }
                     const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull));
                     if (tail) {
-                        uint32_t ts = (word[g] * 0x9E3779B1u) >> (32 - FUSED_TABLE_BITS);
+                        uint32_t ts = (word * 0x9E3779B1u) >> (32 - FUSED_TABLE_BITS);
                         bool stored = false;
 #pragma unroll 1
                         for (int probe = 0; probe < 8; ++probe) {
-                            const uint32_t seen = atomicCAS(&t_word[ts], BITS_EMPTY, word[g]);
-                            if (seen == BITS_EMPTY || seen == word[g]) {
+                            const uint32_t seen = atomicCAS(&t_word[ts], BITS_EMPTY, word);
+                            if (seen == BITS_EMPTY || seen == word) {
                                 atomicOr(&t_bits[ts], b);
                                 stored = true;
                                 break;
                             }
                             ts = (ts + 1) & (FUSED_TABLE - 1);
                         }
-                        if (!stored) atomicOr(&I.leaf[word[g]], b);
+                        if (!stored) atomicOr(&I.leaf[word], b);
                     }
                 }
+                __syncthreads();
+                for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
+                    const uint32_t wd = t_word[t];
+                    if (wd != BITS_EMPTY) atomicOr(&I.leaf[wd], t_bits[t]);
+                }
             }
-            __syncthreads();
-            for (int t = threadIdx.x; t < FUSED_TABLE; t += blockDim.x) {
-                const uint32_t wd = t_word[t];
-                if (wd != BITS_EMPTY) atomicOr(&I.leaf[wd], t_bits[t]);
-            }
-            continue;
         }
+    }
+
+    // ---- pass 2: the scales with a directory (hash form)
+#pragma nounroll
+    for (int32_t sc = 0; sc < n_scales; ++sc) {
+        if (!ladder[sc].valid) continue;
+        const LatticeDev L = ladder[sc].L;
+        const IndexDev I = ladder[sc].I;
+        const bool dense = I.hash == nullptr;
+        __syncthreads();       // the previous scale's flush has read the scratch
+        if (dense) continue;       // done in the first pass
         if (threadIdx.x == 0) won_count = 0u;
         __syncthreads();
 
