@@ -25,6 +25,9 @@ __device__ __forceinline__ double nm_order_decode(uint64_t k)
     return __longlong_as_double((long long)b);
 }
 
+#ifndef NM_BOUNDS_BLOCKS
+#define NM_BOUNDS_BLOCKS 1024
+#endif
 __global__ void k_bounds_init(uint64_t* mm)
 {
     int t = threadIdx.x;
@@ -94,7 +97,7 @@ extern "C" int nm_bounds(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t st
     uint64_t* mm = (uint64_t*)d_minmax;
     k_bounds_init<<<1, 64, 0, s>>>(mm);
     int64_t blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > NM_BOUNDS_BLOCKS) blocks = NM_BOUNDS_BLOCKS;
     k_bounds<<<(int)blocks, 256, 0, s>>>(d_xyz, n, stride, mm);
     k_bounds_finish<<<1, 64, 0, s>>>(mm);
     NM_HIP(ctx, hipGetLastError());
