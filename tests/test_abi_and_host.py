@@ -160,3 +160,41 @@ def test_training_glue_host_side():
         for col in range(3):
             want[row, col] = ((lies == row) * (truth == col)).sum()
     assert np.array_equal(conf, want)
+
+
+def test_forest_node_packing_is_exact_on_the_config5_fixture():
+    """host logic, no GPU: the 8-byte node records of the fused classifier (ForestModel.pack_nodes8) - fp32
+    thresholds rounded DOWN, compared in fp32 - walk to the same leaves as sklearn's fp32-cast features against
+    fp64 thresholds: probabilities of the 4 096 fixture rows to 1e-15, labels equal."""
+    import os
+    from nimrud_amd.minimal.classification import ForestModel
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_forest_c5.npz"))
+    rec, leaf, roots = ForestModel.pack_nodes(g["left"], g["right"], g["feature"], g["threshold"], g["value"],
+                                              g["roots"])
+    p8 = ForestModel.pack_nodes8(rec, 20)
+    assert p8 is not None and p8.dtype.itemsize == 8
+    # the rounding is downwards and tight
+    internal = rec["left"] >= 0
+    t32, t64 = p8["threshold"][internal].astype(np.float64), rec["threshold"][internal]
+    assert np.all(t32 <= t64) and np.all(np.nextafter(p8["threshold"][internal], np.float32(np.inf)) > t64)
+    x = g["x"].astype(np.float32)
+    n = len(x)
+    proba = np.zeros((n, leaf.shape[1]))
+    rows = np.arange(n)
+    packed, thr = p8["packed"], p8["threshold"]
+    for r in roots:
+        node = np.full(n, r, dtype=np.int64)
+        while True:
+            pk = packed[node]
+            active = (pk >> 31) == 0
+            if not active.any():
+                break
+            f = ((pk[active] >> 8) & 31).astype(np.int64)
+            left = (pk[active] >> 13).astype(np.int64)
+            go_left = x[rows[active], f] <= thr[node[active]]          # fp32 against fp32
+            node[active] = left + np.where(go_left, 0, 1)
+        proba += leaf[((packed[node] >> 13) & 0x3FFFF).astype(np.int64)]
+    proba /= len(roots)
+    assert np.abs(proba - g["proba"]).max() <= 1e-15
+    assert np.array_equal(proba.argmax(1), g["label"])
+    assert ForestModel.pack_nodes8(rec, 33) is None             # more features than the 5-bit field holds
