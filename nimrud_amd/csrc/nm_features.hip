@@ -653,7 +653,10 @@ __device__ __forceinline__ void nm_lane_generic(const ScaleArgs& A, const Lattic
 // node = {fp32 threshold, packed}.  internal: left child << 13 | feature << 8, so that
 // (packed & 0x1F00) | lane * 4 already is the LDS byte address of this lane's value of the feature;
 // leaf: bit 31 | row of its class distribution << 13 (bits 8..12 clear: a leaf "reads" feature 0, harmlessly).
-constexpr int NM_FOREST_GROUP = 8;      // trees per group; two groups (16 descents) in flight per lane
+constexpr int NM_FOREST_GROUP = 8;      // trees per group (more than 8 per array: the compiler gives up unrolling)
+#ifndef NM_FOREST_GROUPS
+#define NM_FOREST_GROUPS 2               // groups in flight per lane
+#endif
 
 __device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, const uint2* __restrict__ nodes,
                                                    float* xs, int lane, bool have, uint32_t qi)
@@ -670,64 +673,82 @@ __device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, const uin
     double acc[NM_FUSED_FOREST_CLASSES];
 #pragma unroll
     for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c) acc[c] = 0.0;
-    for (int t0 = 0; t0 < F.n_trees; t0 += 2 * NM_FOREST_GROUP) {
-        // a descent is a chain of dependent steps - LDS read of the feature, compare, node fetch from L2.  the
-        // steps of one level are issued for all trees of both groups before anything is waited for: sixteen
-        // LDS reads, then sixteen node fetches in flight per lane.
+    // a descent is a chain of dependent steps - LDS read of the feature, compare, node fetch from L1/L2 - and
+    // the walk waits on memory most of the time.  the steps of one level are issued for all trees of all
+    // NM_FOREST_GROUPS groups before anything is waited for: that many x 8 LDS reads, then as many node
+    // fetches in flight per lane.  (a branch-free form - finished trees re-fetch their leaf - measured slower:
+    // depths differ, and it pays the deepest tree's levels for all of them.)
+#define NM_FOREST_LOAD(R, OFF)                                                                  \
+    _Pragma("unroll") for (int g = 0; g < NM_FOREST_GROUP; ++g) {                               \
+        const int t = t0 + (OFF) + g < F.n_trees ? t0 + (OFF) + g : F.n_trees - 1;              \
+        R[g] = nodes[F.roots[t]];                                                               \
+    }
+#define NM_FOREST_READ(R, V)                                                                    \
+    _Pragma("unroll") for (int g = 0; g < NM_FOREST_GROUP; ++g)                                 \
+        V[g] = *(const float*)(xsb + ((R[g].y & 0x1F00u) | lane4));
+#define NM_FOREST_STEP(R, V)                                                                    \
+    _Pragma("unroll") for (int g = 0; g < NM_FOREST_GROUP; ++g) {                               \
+        if ((int32_t)R[g].y >= 0) {                                                             \
+            R[g] = nodes[(R[g].y >> 13) + (V[g] <= __uint_as_float(R[g].x) ? 0u : 1u)];         \
+            any = true;                                                                         \
+        }                                                                                       \
+    }
+#define NM_FOREST_VOTE(R, OFF)                                                                  \
+    _Pragma("unroll") for (int g = 0; g < NM_FOREST_GROUP; ++g) {                               \
+        if (t0 + (OFF) + g >= F.n_trees) break;                                                 \
+        const double* val = F.leaf_value + (int64_t)((R[g].y >> 13) & 0x3FFFFu) * F.n_classes;  \
+        _Pragma("unroll") for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)                     \
+            if (c < F.n_classes) acc[c] += val[c];                                              \
+    }
+    for (int t0 = 0; t0 < F.n_trees; t0 += NM_FOREST_GROUPS * NM_FOREST_GROUP) {
         uint2 ra[NM_FOREST_GROUP], rb[NM_FOREST_GROUP];
-#pragma unroll
-        for (int g = 0; g < NM_FOREST_GROUP; ++g) {
-            const int ta = t0 + g < F.n_trees ? t0 + g : F.n_trees - 1;
-            const int tb = t0 + NM_FOREST_GROUP + g < F.n_trees ? t0 + NM_FOREST_GROUP + g : F.n_trees - 1;
-            ra[g] = nodes[F.roots[ta]];
-            rb[g] = nodes[F.roots[tb]];
-        }
-        // (a branch-free form - finished trees re-fetch their leaf, 7 vector instructions per tree and level,
-        // no jumps - measured slower, 2.35 against 2.05 ms for 10 M rows x 32 trees: depths differ, and it
-        // pays the deepest tree's levels for all sixteen)
+        NM_FOREST_LOAD(ra, 0)
+        NM_FOREST_LOAD(rb, NM_FOREST_GROUP)
+#if NM_FOREST_GROUPS >= 3
+        uint2 rc[NM_FOREST_GROUP];
+        NM_FOREST_LOAD(rc, 2 * NM_FOREST_GROUP)
+#endif
+#if NM_FOREST_GROUPS >= 4
+        uint2 rd[NM_FOREST_GROUP];
+        NM_FOREST_LOAD(rd, 3 * NM_FOREST_GROUP)
+#endif
         for (;;) {
             float va[NM_FOREST_GROUP], vb[NM_FOREST_GROUP];
-#pragma unroll
-            for (int g = 0; g < NM_FOREST_GROUP; ++g)
-                va[g] = *(const float*)(xsb + ((ra[g].y & 0x1F00u) | lane4));
-#pragma unroll
-            for (int g = 0; g < NM_FOREST_GROUP; ++g)
-                vb[g] = *(const float*)(xsb + ((rb[g].y & 0x1F00u) | lane4));
+            NM_FOREST_READ(ra, va)
+            NM_FOREST_READ(rb, vb)
+#if NM_FOREST_GROUPS >= 3
+            float vc[NM_FOREST_GROUP];
+            NM_FOREST_READ(rc, vc)
+#endif
+#if NM_FOREST_GROUPS >= 4
+            float vd[NM_FOREST_GROUP];
+            NM_FOREST_READ(rd, vd)
+#endif
             bool any = false;
-#pragma unroll
-            for (int g = 0; g < NM_FOREST_GROUP; ++g) {
-                if ((int32_t)ra[g].y >= 0) {
-                    ra[g] = nodes[(ra[g].y >> 13) + (va[g] <= __uint_as_float(ra[g].x) ? 0u : 1u)];
-                    any = true;
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < NM_FOREST_GROUP; ++g) {
-                if ((int32_t)rb[g].y >= 0) {
-                    rb[g] = nodes[(rb[g].y >> 13) + (vb[g] <= __uint_as_float(rb[g].x) ? 0u : 1u)];
-                    any = true;
-                }
-            }
+            NM_FOREST_STEP(ra, va)
+            NM_FOREST_STEP(rb, vb)
+#if NM_FOREST_GROUPS >= 3
+            NM_FOREST_STEP(rc, vc)
+#endif
+#if NM_FOREST_GROUPS >= 4
+            NM_FOREST_STEP(rd, vd)
+#endif
             if (!any) break;
         }
         // the votes are added in tree order, like sklearn's accumulate-then-divide
-#pragma unroll
-        for (int g = 0; g < NM_FOREST_GROUP; ++g) {
-            if (t0 + g >= F.n_trees) break;
-            const double* val = F.leaf_value + (int64_t)((ra[g].y >> 13) & 0x3FFFFu) * F.n_classes;
-#pragma unroll
-            for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)
-                if (c < F.n_classes) acc[c] += val[c];
-        }
-#pragma unroll
-        for (int g = 0; g < NM_FOREST_GROUP; ++g) {
-            if (t0 + NM_FOREST_GROUP + g >= F.n_trees) break;
-            const double* val = F.leaf_value + (int64_t)((rb[g].y >> 13) & 0x3FFFFu) * F.n_classes;
-#pragma unroll
-            for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)
-                if (c < F.n_classes) acc[c] += val[c];
-        }
+        NM_FOREST_VOTE(ra, 0)
+        NM_FOREST_VOTE(rb, NM_FOREST_GROUP)
+#if NM_FOREST_GROUPS >= 3
+        NM_FOREST_VOTE(rc, 2 * NM_FOREST_GROUP)
+#endif
+#if NM_FOREST_GROUPS >= 4
+        NM_FOREST_VOTE(rd, 3 * NM_FOREST_GROUP)
+#endif
     }
+#undef NM_FOREST_LOAD
+#undef NM_FOREST_READ
+#undef NM_FOREST_STEP
+#undef NM_FOREST_VOTE
     int best = 0;
     double bestv = -1.0;
 #pragma unroll
