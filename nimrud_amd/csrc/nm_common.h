@@ -166,6 +166,7 @@ struct LatticeDev {
     double min_x, min_y, min_z;
     double edge;
     double half_edge;           // edge * 0.5 (exact)
+    double inv_edge;            // fl(1 / edge): the fast path of nm_cell_fast
     int32_t wx, wy, wz;         // address widths (geometry.py:56)
     int32_t s0, s1;             // address shifts (geometry.py:62)
     int32_t bx, by, bz;         // bits of the superblock coordinate per axis: max(w - local, 0)
@@ -180,6 +181,7 @@ static inline LatticeDev make_lattice_dev(const nm_lattice* lat)
     d.min_z = lat->min_corner[2];
     d.edge = lat->edge;
     d.half_edge = lat->edge * 0.5;
+    d.inv_edge = 1.0 / lat->edge;
     d.wx = lat->widths[0];
     d.wy = lat->widths[1];
     d.wz = lat->widths[2];
@@ -269,6 +271,23 @@ constexpr int NM_DENSE_LOG2 = NM_DENSE_LOG2_VALUE;     // a scale with at most 2
 // floor((p - min_corner) / e) exactly as geometry.py:108: fp64 subtract, IEEE divide, floor.
 // compiled with -ffp-contract=off so nothing fuses.
 __device__ __forceinline__ double nm_cell_f(double p, double mn, double e) { return floor((p - mn) / e); }
+
+// the same cell with the division replaced by a multiplication wherever that provably gives the same floor.
+// with x = p - mn (the reference's own subtraction), t = x / e, the reference floors fl(t), |fl(t) - t| <= u|t|
+// (u = 2^-53); q = fl(x * fl(1/e)) has |q - t| <= (2u + u^2)|t|.  so q and fl(t) lie within 3.1 u |q| of each
+// other, and their floors can differ only if an integer lies that close to q.  where q is further than
+// 4 u |q| = |q| 2^-51 from every integer the multiplication's floor IS the reference's; otherwise (also for
+// q = 0 and for non-finite q) the reference's division decides.  lattice-aligned clouds take the slow path
+// for every point; clouds in general position about once in 10^6 points.
+__device__ __forceinline__ double nm_cell_fast(double p, double mn, double e, double inv_e)
+{
+    const double x = p - mn;
+    const double q = x * inv_e;
+    double c = floor(q);
+    const double d = q - rint(q);
+    if (!(fabs(d) > fabs(q) * 0x1p-51)) c = floor(x / e);
+    return c;
+}
 
 // voxel centre exactly as geometry.py:137: (cell * e + min_corner) + e*0.5, left to right
 __device__ __forceinline__ double nm_centre(int32_t cell, double mn, double e, double he)

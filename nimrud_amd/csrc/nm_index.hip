@@ -581,9 +581,9 @@ __global__ __launch_bounds__(256) void k_gather_xyz(const double* __restrict__ x
 
 __device__ __forceinline__ uint64_t nm_point_key(const double* __restrict__ p, const LatticeDev& L)
 {
-    int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
-    int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
-    int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
+    int32_t cx = nm_clamp_cell(nm_cell_fast(p[0], L.min_x, L.edge, L.inv_edge));
+    int32_t cy = nm_clamp_cell(nm_cell_fast(p[1], L.min_y, L.edge, L.inv_edge));
+    int32_t cz = nm_clamp_cell(nm_cell_fast(p[2], L.min_z, L.edge, L.inv_edge));
     cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
     cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
     cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
@@ -1157,6 +1157,7 @@ __global__ void k_make_ladder(const double* __restrict__ minmax, LadderSpec P, S
         L.min_x = mn[0]; L.min_y = mn[1]; L.min_z = mn[2];
         L.edge = e;
         L.half_edge = e * 0.5;
+        L.inv_edge = 1.0 / e;
         L.wx = w[0]; L.wy = w[1]; L.wz = w[2];
         L.s0 = w[0];
         L.s1 = w[0] + w[1];
