@@ -267,7 +267,19 @@ def main():
         dist.init_process_group("gloo")
         from nimrud_amd import parallel
         if not rehearsal:
-            comm = parallel.RcclComm(rank=rank, world=world, device=dev)
+            # every rank must end up on the same transport: agree (over gloo) on whether RCCL came up
+            try:
+                comm = parallel.RcclComm(rank=rank, world=world, device=dev)
+                ok = 1
+            except Exception as err:       # noqa: BLE001
+                print("rank %d: RCCL communicator could not be created (%s); falling back to "
+                      "torch.distributed over gloo" % (rank, str(err)[:200]), file=sys.stderr)
+                comm, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
 
     cloud = torch.from_numpy(tile).to(dev)
     rt = nm_device.get_runtime(dev)
