@@ -451,7 +451,9 @@ def main():
                 "collectives": "none" if world == 1 else
                                ("nm_halo_exchange over RCCL: all-gather(6 f64) + all-gather(256 KB cell set) "
                                 "+ all-gather(counts) + grouped ncclSend/ncclRecv(halo rows) per step"
-                                if comm is not None else "torch.distributed over gloo (rehearsal)"),
+                                if comm is not None else ("torch.distributed over gloo (rehearsal)" if rehearsal
+                                      else "torch.distributed over gloo, staged through host memory "
+                                           "(the RCCL communicator could not be created)")),
             },
             "roofline": roofline,
             "stage_ms_per_step": {
