@@ -541,6 +541,29 @@ constexpr RowBoundTable nm_make_bounds(double rho2, bool prune)
 // tests that can matter
 constexpr RowBoundTable NM_BOUNDS_RHO3 = nm_make_bounds<7>(9.0, true);
 
+// ceil(2^20 / n) for the divisors the staging loops use (n <= ROWS_CAP): (t * v[n]) >> 20 is t / n, exactly,
+// for every operand the loops form (t < ROWS_CAP; the static_assert below goes through all of them)
+struct Recip20 {
+    uint32_t v[ROWS_CAP + 1];
+};
+constexpr Recip20 nm_make_recip()
+{
+    Recip20 t{};
+    t.v[0] = 0u;
+    for (uint32_t n = 1; n <= ROWS_CAP; ++n) t.v[n] = ((1u << 20) + n - 1u) / n;
+    return t;
+}
+constexpr bool nm_recip_exact()
+{
+    const Recip20 t = nm_make_recip();
+    for (uint32_t n = 1; n <= ROWS_CAP; ++n)
+        for (uint32_t x = 0; x < (uint32_t)ROWS_CAP; ++x)
+            if (((x * t.v[n]) >> 20) != x / n) return false;
+    return true;
+}
+static_assert(nm_recip_exact(), "the 20-bit reciprocals must divide every operand below ROWS_CAP exactly");
+__device__ const Recip20 NM_RECIP20 = nm_make_recip();
+
 // packed LUT fields: bits [0,8) count, [8,20) sum of bit index, [20,32) sum of index^2
 template <int W>
 struct MomentLut {
@@ -789,6 +812,35 @@ __global__ __launch_bounds__(64) void k_forest_ordered(ScaleArgs A, const uint2*
 #ifndef NM_SEARCH_ATTR
 #define NM_SEARCH_ATTR
 #endif
+// a * k + c through the full-rate 24-bit multiplier, for a constant k and a sum whose low bits are all that
+// is read: written as C the compiler sees that only low bits are needed, drops the "24-bit" and picks
+// v_mul_lo_u32 (quarter rate) for k = 3, 5, 6
+__device__ __forceinline__ uint32_t nm_mad24(uint32_t a, uint32_t k, uint32_t c)
+{
+    if (k == 0u) return c;
+    if (k == 1u) return a + c;
+    if ((k & (k - 1u)) == 0u) return (a << __builtin_ctz(k)) + c;
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(k), "v"(c));
+    return r;
+}
+
+// a * b + c for small signed numbers (the compiler turns __mul24(a, b) + c into v_mad_u64_u32, quarter rate)
+__device__ __forceinline__ int32_t nm_mad24i(int32_t a, int32_t b, int32_t c)
+{
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// base + row * stride + col with one 32 x 32 -> 64 multiply-add (rows and strides are below 2^31, checked
+// on the host)
+template <typename T>
+__device__ __forceinline__ T* nm_row_ptr(T* base, uint32_t row, int64_t stride, int32_t col)
+{
+    return base + ((uint64_t)row * (uint64_t)(uint32_t)stride + (uint64_t)(uint32_t)col);
+}
+
 template <int W, bool RHO3, bool FOREST, bool LOOP>
 __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs A, RowBoundTable RT,
                                                        const ScaleDev* __restrict__ scales,
@@ -831,7 +883,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         have = qi < A.nq;    // prefix mode: the sorted order also holds the non-query search rows
     }
     if (have) {
-        const double* p = A.query + (A.direct ? slot : (int64_t)qi) * A.qstride;
+        const double* p = nm_row_ptr(A.query, A.direct ? (uint32_t)slot : qi, A.qstride, 0);
         qx = p[0];
         qy = p[1];
         qz = p[2];
@@ -854,17 +906,17 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                      hy + dmin >= (1 << L.wy) || hz + dmax < 0 || hz + dmin >= (1 << L.wz);
     bool done = !have || far;
     if (have && far) {
-        double* o = A.feat + (int64_t)qi * A.fstride + 4 * s;
+        double* o = nm_row_ptr(A.feat, qi, A.fstride, 4 * s);
         o[0] = 0.0;
         o[1] = 0.0;
         o[2] = 0.0;
         o[3] = 0.0;
         if (A.cov) {
-            double* c = A.cov + (int64_t)qi * A.cstride + 6 * s;
+            double* c = nm_row_ptr(A.cov, qi, A.cstride, 6 * s);
             c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = 0.0;
         }
         if (A.normal) {
-            double* v = A.normal + (int64_t)qi * A.nstride + 3 * s;
+            double* v = nm_row_ptr(A.normal, qi, A.nstride, 3 * s);
             v[0] = v[1] = v[2] = 0.0;
         }
     }
@@ -992,14 +1044,22 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             fits = 3 * nsy * nsz <= SBT_CAP;
         }
         if (!fits) {
+            // (readlane, not a shuffle: the box stays in scalar registers and so does everything derived
+            // from it)
             const int anchor = __ffsll((long long)todo) - 1;
-            const int32_t ax = __shfl(hx, anchor), ay = __shfl(hy, anchor), az = __shfl(hz, anchor);
+            const int32_t ax = __builtin_amdgcn_readlane(hx, anchor), ay = __builtin_amdgcn_readlane(hy, anchor),
+                          az = __builtin_amdgcn_readlane(hz, anchor);
             ox = ax + dmin - (NM_BOX_EX - W) / 2;
             oy = ay + dmin - (ANCHOR_EYZ - W) / 2;
             oz = az + dmin - (ANCHOR_EYZ - W) / 2;
             ey = ANCHOR_EYZ;
             ez = ANCHOR_EYZ;
         }
+        ox = __builtin_amdgcn_readfirstlane(ox);
+        oy = __builtin_amdgcn_readfirstlane(oy);
+        oz = __builtin_amdgcn_readfirstlane(oz);
+        ey = __builtin_amdgcn_readfirstlane(ey);
+        ez = __builtin_amdgcn_readfirstlane(ez);
         const bool sel = !done && hx + dmin >= ox && hx + dmax < ox + NM_BOX_EX && hy + dmin >= oy &&
                          hy + dmax < oy + ey && hz + dmin >= oz && hz + dmax < oz + ez;
 
@@ -1010,15 +1070,15 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         const int32_t sbx0 = (ox - 2) >> NM_SBX_BITS, sby0 = oy >> NM_SBY_BITS, sbz0 = oz >> NM_SBZ_BITS;
         const int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - sby0 + 1;
         const int32_t nsz = ((oz + ez - 1) >> NM_SBZ_BITS) - sbz0 + 1;
-        const int32_t nsb = 3 * nsy * nsz;
-        const uint32_t inv_nsy = ((1u << 20) + (uint32_t)nsy - 1u) / (uint32_t)nsy;
-        const uint32_t inv_ey = ((1u << 20) + (uint32_t)ey - 1u) / (uint32_t)ey;
+        const int32_t nsb = __builtin_amdgcn_readfirstlane(3 * nsy * nsz);
+        const uint32_t inv_nsy = NM_RECIP20.v[nsy];     // (two scalar loads; the divisions cost 50 vector
+        const uint32_t inv_ey = NM_RECIP20.v[ey];       //  instructions per pass, eight of them quarter rate)
 #pragma nounroll
         for (int32_t t = lane; t < nsb; t += 64) {
-            const uint32_t t3 = ((uint32_t)t * 0x5556u) >> 16;        // t / 3 for t < 2^15
+            const uint32_t t3 = __umul24((uint32_t)t, 0x5556u) >> 16;  // t / 3 for t < 2^15
             const int32_t ix = t - 3 * (int32_t)t3;
-            const uint32_t iz = (t3 * inv_nsy) >> 20;                  // t3 / nsy
-            const int32_t iy = (int32_t)t3 - (int32_t)iz * nsy;
+            const uint32_t iz = __umul24(t3, inv_nsy) >> 20;           // t3 / nsy
+            const int32_t iy = (int32_t)t3 - __mul24((int32_t)iz, nsy);
             int32_t sx = sbx0 + ix, sy = sby0 + iy, sz = sbz0 + (int32_t)iz;
             bool ok = sx >= 0 && sy >= 0 && sz >= 0 && sx < (1 << L.bx) && sy < (1 << L.by) &&
                       sz < (1 << L.bz);
@@ -1031,9 +1091,10 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         const uint32_t sh = (uint32_t)((ox - 2) & 31);
 #pragma nounroll
         for (int32_t rr = lane; rr < nrows; rr += 64) {
-            const int32_t rz = (int32_t)(((uint32_t)rr * inv_ey) >> 20);   // rr / ey (rr < 512)
-            const int32_t y = oy + (rr - rz * ey), z = oz + rz;
-            int32_t t0 = (((z >> NM_SBZ_BITS) - sbz0) * nsy + ((y >> NM_SBY_BITS) - sby0)) * 3;
+            const int32_t rz = (int32_t)(__umul24((uint32_t)rr, inv_ey) >> 20);   // rr / ey (rr < 512)
+            const int32_t y = oy + (rr - __mul24(rz, ey)), z = oz + rz;
+            const int32_t c0 = nm_mad24i((z >> NM_SBZ_BITS) - sbz0, nsy, (y >> NM_SBY_BITS) - sby0);
+            const int32_t t0 = __mul24(c0, 3);
             uint32_t wofs = (uint32_t)((z & 7) * 8 + (y & 7));
             int32_t l0 = sbt[t0], l1 = sbt[t0 + 1], l2 = sbt[t0 + 2];
             uint32_t w0 = l0 >= 0 ? I.leaf[(size_t)l0 * NM_LEAF_WORDS + wofs] : 0u;
@@ -1050,8 +1111,10 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         if (sel) {
             const int32_t rx = hx + dmin - ox;
             // row of the home cell, and the lane's signed strides through the mirrored window
-            const int32_t rhome = (hz - oz) * ey + (hy - oy);
-            const int32_t step_z = sgn_z * ey, step_y = sgn_y;
+            // (byte offsets; 24-bit multiplies are full rate, 32-bit ones a quarter)
+            const int32_t rhome8 = (__mul24(hz - oz, ey) + (hy - oy)) << 3;
+            const int32_t step_z8 = (sgn_z < 0 ? -ey : ey) << 3, step_y8 = sgn_y << 3;
+            const unsigned char* rows8 = (const unsigned char*)rows;
             uint32_t aj[W], bk[W], cj[W];
 #pragma unroll
             for (int i = 0; i < W; ++i) aj[i] = bk[i] = cj[i] = 0u;
@@ -1067,7 +1130,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
                     if (RHO3 && NM_BOUNDS_RHO3.rb[j * W + k].b < 0) continue;
-                    const uint64_t row = rows[rhome + (k - C) * step_z + (j - C) * step_y];
+                    const uint64_t row = *(const uint64_t*)(
+                        rows8 + (__mul24(k - C, step_z8) + (rhome8 + __mul24(j - C, step_y8))));
                     const int r = j * W + k;
                     const uint32_t in4 = (inside[r / ROWS_PER_REG] >> ((r % ROWS_PER_REG) * W)) &
                                          (((1u << W) - 1u) << 2);
@@ -1079,8 +1143,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                     const uint32_t t = lut[valid[k] >> 2];
                     aj[j] += t;
                     bk[k] += t;
-                    if (W <= 7)
-                        cj[j] += t * (uint32_t)k;          // low 8 bits = sum k*n (< 256 for W <= 7)
+                    if (W <= 7)       // low 8 bits = sum k*n (< 256 for W <= 7); a 24-bit multiply keeps them
+                        cj[j] = nm_mad24(t, (uint32_t)k, cj[j]);
                     else
                         cj[j] += (t & 0xFFu) * (uint32_t)k;
                 }
@@ -1125,7 +1189,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         nm_features_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
                                  (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
                                  (double)m_syz, (double)m_szz, ux, uy, uz, (double)dmin, L.edge, out);
-        double* o = A.feat + (int64_t)qi * A.fstride + 4 * s;
+        double* o = nm_row_ptr(A.feat, qi, A.fstride, 4 * s);
         o[0] = out[0];
         o[1] = out[1];
         o[2] = out[2];
@@ -1134,12 +1198,12 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             nm_covariance_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
                                        (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
                                        (double)m_syz, (double)m_szz, (double)sgn_y, (double)sgn_z,
-                                       L.edge, A.cov + (int64_t)qi * A.cstride + 6 * s);
+                                       L.edge, nm_row_ptr(A.cov, qi, A.cstride, 6 * s));
         if (A.normal)
             nm_normal_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz, (double)m_sxx,
                                    (double)m_sxy, (double)m_sxz, (double)m_syy, (double)m_syz,
                                    (double)m_szz, (double)sgn_y, (double)sgn_z,
-                                   A.normal + (int64_t)qi * A.nstride + 3 * s);
+                                   nm_row_ptr(A.normal, qi, A.nstride, 3 * s));
     }
     const unsigned long long degenerate = __ballot(emit && m_n < 2u);
     if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
@@ -1533,6 +1597,11 @@ static int check_scale_args(nm_ctx* ctx, const char* who, const double* d_query,
         NM_FAIL(ctx, NM_ERR_INVALID, "%s: bad arguments", who);
     if (n_query > 0 && (!d_query || !d_feat || query_stride < 3))
         NM_FAIL(ctx, NM_ERR_INVALID, "%s: bad query/feature arguments", who);
+    // row strides are multiplied as 32-bit numbers on the device (one multiply-add per address)
+    const int64_t lim = (int64_t)1 << 31;
+    if (query_stride >= lim || search_stride >= lim || feat_stride >= lim || ctx->cov_stride >= lim ||
+        ctx->normal_stride >= lim)
+        NM_FAIL(ctx, NM_ERR_INVALID, "%s: a row stride of 2^31 elements or more", who);
     return NM_OK;
 }
 
