@@ -541,6 +541,50 @@ constexpr RowBoundTable nm_make_bounds(double rho2, bool prune)
 // tests that can matter
 constexpr RowBoundTable NM_BOUNDS_RHO3 = nm_make_bounds<7>(9.0, true);
 
+// ---- the inside/outside masks of a query's window, as the search kernel packs them -------------------------
+// row (j, k) of the window has W bits, candidate c in bit 2 + (k % RPR) * W + c of register j * RPJ + k / RPR
+// (RPR = 30 / W rows to a register, every y-slab j starts a register of its own).
+// for r = 3e the tests of one register form a compile-time chain: going down from the highest tested bit, every
+// test enters the register with ONE v_alignbit whose shift is the distance to the next tested bit below it
+//     x = (x << d) | (hi(t) >> (32 - d))          sign of t = "outside", lands on bit d - 1
+// so after the last test (d = its position + 1) every sign sits on its candidate's bit.  the bits in between hold
+// exponent bits of some t: they belong to candidates that are always or never inside, and the closing
+// (~x & tested) | always  (one v_bitop3) overwrites them.
+constexpr int NM_RHO3_W = 7, NM_RHO3_RPR = 30 / NM_RHO3_W, NM_RHO3_RPJ = (NM_RHO3_W + NM_RHO3_RPR - 1) / NM_RHO3_RPR;
+struct ChainTable {
+    int8_t d[NM_RHO3_W][NM_RHO3_W][NM_RHO3_W];            // [j][k][i]: alignbit distance, 0 = not tested
+    uint32_t tested[NM_RHO3_W * NM_RHO3_RPJ];
+    uint32_t always[NM_RHO3_W * NM_RHO3_RPJ];
+};
+constexpr ChainTable nm_make_chain(const RowBoundTable& B)
+{
+    constexpr int W = NM_RHO3_W, C = (W - 1) / 2, RPR = NM_RHO3_RPR, RPJ = NM_RHO3_RPJ;
+    ChainTable t{};
+    for (int j = 0; j < W; ++j)
+        for (int h = 0; h < RPJ; ++h) {
+            int prev_k = -1, prev_i = -1, prev_p = -1;          // the tested bit above the current one
+            for (int k = (h + 1) * RPR < W ? (h + 1) * RPR - 1 : W - 1; k >= h * RPR; --k) {
+                const RowBound rb = B.rb[j * W + k];
+                for (int i = W - 1; i >= 0; --i) {
+                    const int ad = i > C ? i - C : C - i;
+                    const int p = 2 + (k % RPR) * W + i;
+                    if (rb.b < 0 || ad > rb.b) continue;
+                    if (ad <= rb.a) {
+                        t.always[j * RPJ + h] |= 1u << p;
+                        continue;
+                    }
+                    t.tested[j * RPJ + h] |= 1u << p;
+                    if (prev_p >= 0) t.d[j][prev_k][prev_i] = (int8_t)(prev_p - p);
+                    prev_k = k; prev_i = i; prev_p = p;
+                }
+            }
+            if (prev_p >= 0) t.d[j][prev_k][prev_i] = (int8_t)(prev_p + 1);
+        }
+    return t;
+}
+
+constexpr ChainTable NM_CHAIN_RHO3 = nm_make_chain(NM_BOUNDS_RHO3);
+
 // ceil(2^20 / n) for the divisors the staging loops use (n <= ROWS_CAP): (t * v[n]) >> 20 is t / n, exactly,
 // for every operand the loops form (t < ROWS_CAP; the static_assert below goes through all of them)
 struct Recip20 {
@@ -849,8 +893,10 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     static_assert(W >= 3 && W <= 9 && (W & 1), "LUT kernel covers W = 3,5,7,9");
     static_assert(!RHO3 || W == 7, "the compile-time table is for W = 7");
     constexpr int C = (W - 1) / 2;
-    constexpr int ROWS_PER_REG = 30 / W;                          // packed mask fields per VGPR, from bit 2
-    constexpr int MASK_REGS = (W * W + ROWS_PER_REG - 1) / ROWS_PER_REG;
+    constexpr int RPR = 30 / W;                   // rows of the window per mask register, from bit 2
+    constexpr int RPJ = (W + RPR - 1) / RPR;      // mask registers per y-slab
+    constexpr int MASK_REGS = W * RPJ;
+    static_assert(!RHO3 || (RPR == NM_RHO3_RPR && RPJ == NM_RHO3_RPJ), "layout of the compile-time chains");
     // one block of LDS: the staged rows, the superblock table and the moment table; the classifier's
     // feature stage reuses all of it after the last scale
     constexpr int SEARCH_BYTES = ROWS_CAP * 8 + SBT_CAP * 4 + (4 << W);
@@ -949,7 +995,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     const int32_t sgn_z = uz_home < 0.0 ? -1 : 1;
 
     // ---- phase A (once per wave and scale): the inside/outside bit of every candidate that needs a test,
-    //      as W-bit row masks packed ROWS_PER_REG to a register.  independent of the occupancy.
+    //      as W-bit row masks packed RPR to a register.  independent of the occupancy.
     uint32_t inside[MASK_REGS];
     {
         // squared coordinate differences to the W candidate centres per axis (bit-identical centres)
@@ -986,29 +1032,47 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             double pxy[W];
 #pragma unroll
             for (int i = 0; i < W; ++i) pxy[i] = dx2[i] + dy2[j];
+            if constexpr (RHO3) {
+                // compile-time chains (see ChainTable): one v_alignbit per test, one v_bitop3 per register
 #pragma unroll
-            for (int k = 0; k < W; ++k) {
-                const RowBound rb = RHO3 ? NM_BOUNDS_RHO3.rb[j * W + k] : RT.rb[j * W + k];
-                // "outside" bits of the candidates C-b .. C+b (the ones further out are never inside: their
-                // bits of the row mask simply stay clear), candidate C-b in bit 0
-                if (rb.b < 0) continue;
-                uint32_t outside = 0u;
+                for (int h = 0; h < RPJ; ++h) {
+                    uint32_t x = 0u;
 #pragma unroll
-                for (int i = W - 1; i >= 0; --i) {
-                    const int ad = i > C ? i - C : C - i;
-                    if (ad > rb.b) continue;
-                    if (ad <= rb.a) {
-                        outside = outside << 1;
-                    } else {
-                        const double sq = pxy[i] + dz2[k];
-                        const double t = r2 - sq;      // sign bit set  <=>  sq > r^2  (exact)
-                        outside = __builtin_amdgcn_alignbit(outside, (uint32_t)__double2hiint(t), 31);
+                    for (int k = ((h + 1) * RPR < W ? (h + 1) * RPR : W) - 1; k >= h * RPR; --k) {
+#pragma unroll
+                        for (int i = W - 1; i >= 0; --i) {
+                            const int d = NM_CHAIN_RHO3.d[j][k][i];
+                            if (d == 0) continue;
+                            const double sq = pxy[i] + dz2[k];
+                            const double t = r2 - sq;      // sign bit set  <=>  sq > r^2  (exact)
+                            x = __builtin_amdgcn_alignbit(x, (uint32_t)__double2hiint(t), 32 - d);
+                        }
                     }
+                    inside[j * RPJ + h] = (~x & NM_CHAIN_RHO3.tested[j * RPJ + h]) | NM_CHAIN_RHO3.always[j * RPJ + h];
                 }
-                const uint32_t span = (1u << (2 * rb.b + 1)) - 1u;
-                const int row = j * W + k;
-                inside[row / ROWS_PER_REG] |= ((~outside) & span)
-                                              << ((row % ROWS_PER_REG) * W + 2 + (C - rb.b));
+            } else {
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const RowBound rb = RT.rb[j * W + k];
+                    // "outside" bits of the candidates C-b .. C+b (the ones further out are never inside: their
+                    // bits of the row mask simply stay clear), candidate C-b in bit 0
+                    if (rb.b < 0) continue;
+                    uint32_t outside = 0u;
+#pragma unroll
+                    for (int i = W - 1; i >= 0; --i) {
+                        const int ad = i > C ? i - C : C - i;
+                        if (ad > rb.b) continue;
+                        if (ad <= rb.a) {
+                            outside = outside << 1;
+                        } else {
+                            const double sq = pxy[i] + dz2[k];
+                            const double t = r2 - sq;      // sign bit set  <=>  sq > r^2  (exact)
+                            outside = __builtin_amdgcn_alignbit(outside, (uint32_t)__double2hiint(t), 31);
+                        }
+                    }
+                    const uint32_t span = (1u << (2 * rb.b + 1)) - 1u;
+                    inside[j * RPJ + k / RPR] |= ((~outside) & span) << ((k % RPR) * W + 2 + (C - rb.b));
+                }
             }
             // keep the rows of different j apart: without this the scheduler interleaves all W*W
             // chains and the live set (W*W partial sums) costs two waves of occupancy
@@ -1133,7 +1197,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                     const uint64_t row = *(const uint64_t*)(
                         rows8 + (__mul24(k - C, step_z8) + (rhome8 + __mul24(j - C, step_y8))));
                     const int r = j * W + k;
-                    const uint32_t in4 = (inside[r / ROWS_PER_REG] >> ((r % ROWS_PER_REG) * W)) &
+                    const uint32_t in4 = (inside[j * RPJ + k / RPR] >> ((k % RPR) * W)) &
                                          (((1u << W) - 1u) << 2);
                     valid[k] = (uint32_t)(row >> rx) & in4;      // 4 * (occupied & inside)
                 }
