@@ -13,6 +13,7 @@
  *     as (d_work, work_bytes); its required size comes from the matching *_workspace_bytes function.
  *   - point clouds are row-major fp64 arrays; `stride` is the row pitch in doubles (>= 3), so a
  *     (N, 3+F) cloud with feature columns is passed without a copy (minimal/README.md:38-40).
+ *     the feature entry points take row pitches below 2^31 doubles (NM_ERR_INVALID otherwise).
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
  *     unless documented otherwise, and returns NM_OK or a negative nm_status.
  *     nm_last_error(ctx) returns a human-readable message for the last failure on that context.

@@ -40,8 +40,26 @@ __global__ __launch_bounds__(256) void k_bounds(const double* __restrict__ xyz, 
 {
     double lo[3] = {INFINITY, INFINITY, INFINITY};
     double hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    // four rows in flight per thread (the loop is bound by the latency of its loads, not by their number)
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * step < n; i += 4 * step) {
+        double v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double* p = xyz + (i + u * step) * stride;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[u][a] = p[a];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fmin(lo[a], v[u][a]);
+                hi[a] = fmax(hi[a], v[u][a]);
+            }
+    }
+    for (; i < n; i += step) {
         const double* p = xyz + i * stride;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {

@@ -645,6 +645,19 @@ def test_ladder_argument_checks():
     with pytest.raises(ValueError):
         multiscale.process_gpu(dev, dev, [0.1], [0.3], normal_out=torch.zeros((3000, 3), dtype=torch.float32,
                                                                               device="cuda"))
+    # row strides are 32-bit on the device: 2^31 elements or more is refused before anything is launched
+    import ctypes
+    from nimrud_amd import _ffi, device as nm_device
+    rt = _device_runtime()
+    e1, r1 = (ctypes.c_double * 1)(0.1), (ctypes.c_double * 1)(0.3)
+    work = torch.empty(int(rt.lib.nm_ladder_workspace_bytes(3000, 3000, 1)), dtype=torch.uint8, device="cuda")
+    out = torch.zeros((3000, 4), dtype=torch.float64, device="cuda")
+    rc = rt.lib.nm_ladder_features(rt.ctx, nm_device.ptr(dev), 3000, 3, nm_device.ptr(dev), 3000, 3, e1, r1, 1,
+                                   None, nm_device.ptr(out), 1 << 31, None, nm_device.ptr(work), work.numel(),
+                                   rt.stream())
+    assert rc == _ffi.NM_ERR_INVALID
+    assert b"stride" in rt.lib.nm_last_error(rt.ctx)
+    assert float(out.abs().sum()) == 0.0
     # and the library is still usable afterwards
     got = multiscale.process_gpu(dev, dev, [0.1], [0.3]).cpu().numpy()
     assert_features_close(got, oracle.process_fast(pts, pts, [0.1], [0.3]), pts)
