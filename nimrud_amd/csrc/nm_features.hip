@@ -1196,7 +1196,6 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                     if (RHO3 && NM_BOUNDS_RHO3.rb[j * W + k].b < 0) continue;
                     const uint64_t row = *(const uint64_t*)(
                         rows8 + (__mul24(k - C, step_z8) + (rhome8 + __mul24(j - C, step_y8))));
-                    const int r = j * W + k;
                     const uint32_t in4 = (inside[j * RPJ + k / RPR] >> ((k % RPR) * W)) &
                                          (((1u << W) - 1u) << 2);
                     valid[k] = (uint32_t)(row >> rx) & in4;      // 4 * (occupied & inside)
@@ -1832,6 +1831,7 @@ struct LadderLayout {
     size_t q_key_tmp, q_val_tmp, q_key, q_order, q_xyz;
     size_t sort_temp, sort_temp_bytes;
     size_t minmax;                   // 6 doubles: the search cloud's extrema
+    size_t bounds_scratch;           // the bounds pass's per-block extrema
     size_t ladder;                   // ScaleDev[n_scales]
     size_t order_dev;                // OrderDev
     size_t hash[NM_MAX_LADDER], leaf[NM_MAX_LADDER], counters[NM_MAX_LADDER];
@@ -1865,6 +1865,7 @@ static void ladder_layout(int64_t nq, int64_t ns, int n_scales, bool shared, boo
     S->sort_temp_bytes = nm_sort_pairs_temp_bytes(ns > nq ? ns : nq);
     S->sort_temp = take(S->sort_temp_bytes);
     S->minmax = take(64);
+    S->bounds_scratch = take(NM_BOUNDS_SCRATCH_BYTES);
     S->ladder = take(sizeof(ScaleDev) * (size_t)NM_MAX_LADDER);
     S->order_dev = take(sizeof(OrderDev));
     uint64_t cap = (uint64_t)(ns > 1 ? ns : 1);
@@ -2129,7 +2130,8 @@ extern "C" int nm_ladder_features(nm_ctx* ctx, const double* d_query, int64_t n_
     // global extrema of a multi-GPU job), then one tiny kernel turns them into every scale's lattice
     const double* mm = d_minmax;
     if (!mm) {
-        rc = nm_bounds(ctx, d_search, n_search, search_stride, (double*)(w + S.minmax), stream);
+        rc = nm_bounds_scratch(ctx, d_search, n_search, search_stride, (double*)(w + S.minmax),
+                               w + S.bounds_scratch, s);
         if (rc) return rc;
         mm = (const double*)(w + S.minmax);
     }

@@ -28,6 +28,11 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
                    uint32_t* val_tmp, uint32_t* key_sorted, uint32_t* order, void* sort_temp,
                    size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
 
+// the extrema of a cloud (nm_bounds) with NM_BOUNDS_SCRATCH_BYTES of caller scratch: no atomics
+constexpr size_t NM_BOUNDS_SCRATCH_BYTES = 1024 * 6 * 8;
+int nm_bounds_scratch(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, double* d_minmax,
+                      void* d_partial, hipStream_t s);
+
 // the device-resident scale array: from host lattices, or from the cloud's extrema on the device
 // leaf_alloc: leaves the workspace has room for per scale (> 0: coarse scales may be indexed densely);
 // 0: keep every index exactly as the host sized it (the one-scale path)
