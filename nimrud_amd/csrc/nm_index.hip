@@ -322,6 +322,16 @@ __global__ __launch_bounds__(UNIQ_BLOCK) void k_unique_write(const uint64_t* __r
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// rocPRIM's radix sort hands anything up to 2^20 items to a merge sort (block sort + ten merge passes at
+// 1 M items: 21 launches, 164 us); its onesweep radix passes are faster from a few hundred thousand items
+// (measured on MI355X, order stage of a step: 1 M points 0.208 -> 0.188 ms; at 100 k points onesweep's fixed
+// cost makes it 0.143 against 0.073 ms, so small clouds stay on the merge sort)
+#ifndef NM_MERGE_SORT_LIMIT
+#define NM_MERGE_SORT_LIMIT 262144
+#endif
+using NmSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::default_config, NM_MERGE_SORT_LIMIT>;
+
 static size_t sort_keys_temp_bytes(int64_t n)
 {
     size_t temp = 0;
@@ -333,11 +343,11 @@ static size_t sort_keys_temp_bytes(int64_t n)
 size_t nm_sort_pairs_temp_bytes(int64_t n)
 {
     size_t temp = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr,
+    (void)rocprim::radix_sort_pairs<NmSortConfig>(nullptr, temp, (uint64_t*)nullptr, (uint64_t*)nullptr,
                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 64,
                                     (hipStream_t)0);
     size_t temp32 = 0;      // nm_order_build sorts 32-bit keys when they fit
-    (void)rocprim::radix_sort_pairs(nullptr, temp32, (uint32_t*)nullptr, (uint32_t*)nullptr,
+    (void)rocprim::radix_sort_pairs<NmSortConfig>(nullptr, temp32, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32,
                                     (hipStream_t)0);
     return temp > temp32 ? temp : temp32;
@@ -592,7 +602,7 @@ int nm_sort_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, c
                   void* sort_temp, size_t sort_temp_bytes, hipStream_t s)
 {
     k_cell_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, L, key_tmp, val_tmp);
-    NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp,
+    NM_HIP(ctx, rocprim::radix_sort_pairs<NmSortConfig>(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp,
                                           val_sorted, (size_t)n, 0, (unsigned)L.keybits, s));
     return NM_OK;
 }
@@ -1111,7 +1121,7 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
     // the compact key always fits 32 bits (31 at 10 M points of the benchmark scene): the sort moves 8
     // bytes per pair and pass
     k_order_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, d_order_dev, key_tmp, val_tmp);
-    NM_HIP(ctx, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp, order,
+    NM_HIP(ctx, rocprim::radix_sort_pairs<NmSortConfig>(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp, order,
                                           (size_t)n, 0, sort_bits, s));
     k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
     NM_HIP(ctx, hipGetLastError());
