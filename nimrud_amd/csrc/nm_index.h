@@ -28,6 +28,13 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
                    uint32_t* val_tmp, uint32_t* key_sorted, uint32_t* order, void* sort_temp,
                    size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
 
+// bits of the spatial order's sort key (a wider key loses its low bits): three radix passes of 10 bits.
+// (the benchmark scene's finest lattice has 31: the one bit makes no measurable difference to the index
+// build or the search; round 1 measured that six do)
+#ifndef NM_ORDER_KEY_BITS
+#define NM_ORDER_KEY_BITS 30
+#endif
+
 // the extrema of a cloud (nm_bounds) with NM_BOUNDS_SCRATCH_BYTES of caller scratch: no atomics
 constexpr size_t NM_BOUNDS_SCRATCH_BYTES = 1024 * 6 * 8;
 int nm_bounds_scratch(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, double* d_minmax,

@@ -331,6 +331,21 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 #endif
 using NmSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                                 rocprim::default_config, NM_MERGE_SORT_LIMIT>;
+// the spatial order's (key, row) pairs, both 32 bits: keys of NM_ORDER_KEY_BITS = 30 bits in THREE onesweep
+// passes of 10 bits.  (rocPRIM's tuned gfx950 entry for this type pair is 8 bits x 1024 threads x 16 items:
+// four passes, 0.655 ms for the order stage of the 10 M-point benchmark step; 10 bits x 1024 x 12: 0.545 ms.
+// 11 bits does not fit the rank kernel's LDS; blocks of 512 or 256 threads are slower at every item count.)
+#ifndef NM_ONESWEEP_BITS
+#define NM_ONESWEEP_BITS 10
+#define NM_ONESWEEP_BLOCK 1024
+#define NM_ONESWEEP_ITEMS 12
+#endif
+using NmOnesweep32 = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>,
+                                                         rocprim::kernel_config<NM_ONESWEEP_BLOCK, NM_ONESWEEP_ITEMS>,
+                                                         NM_ONESWEEP_BITS,
+                                                         rocprim::block_radix_rank_algorithm::match>;
+using NmSortConfig32 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  NmOnesweep32, NM_MERGE_SORT_LIMIT>;
 
 static size_t sort_keys_temp_bytes(int64_t n)
 {
@@ -347,7 +362,7 @@ size_t nm_sort_pairs_temp_bytes(int64_t n)
                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 64,
                                     (hipStream_t)0);
     size_t temp32 = 0;      // nm_order_build sorts 32-bit keys when they fit
-    (void)rocprim::radix_sort_pairs<NmSortConfig>(nullptr, temp32, (uint32_t*)nullptr, (uint32_t*)nullptr,
+    (void)rocprim::radix_sort_pairs<NmSortConfig32>(nullptr, temp32, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 32,
                                     (hipStream_t)0);
     return temp > temp32 ? temp : temp32;
@@ -1075,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_order_keys(const double* __restrict__ x
         } else {
             k = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
         }
-        // the order only has to be spatially coherent: a key wider than 32 bits loses its low bits (the
+        // the order only has to be spatially coherent: a key wider than NM_ORDER_KEY_BITS loses its low bits (the
         // points of a small block of finest cells then stay in input order)
         k >>= O.shift;
     }
@@ -1083,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_order_keys(const double* __restrict__ x
     val[i] = (uint32_t)i;
 }
 
-// the spatial order of a lattice: which key, how its bits are laid out, what is dropped to fit 32 bits
+// the spatial order of a lattice: which key, how its bits are laid out, what is dropped to fit the sort key
 __host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O)
 {
     O->L = L;
@@ -1107,7 +1122,7 @@ __host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O)
         }
     }
     const int bits = O->morton ? L.wx + L.wy + L.wz : L.keybits;
-    O->shift = bits > 32 ? bits - 32 : 0;
+    O->shift = bits > NM_ORDER_KEY_BITS ? bits - NM_ORDER_KEY_BITS : 0;
     O->valid = 1;
 }
 
@@ -1117,11 +1132,11 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
                    size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s)
 {
     if (sort_bits < 1) sort_bits = 1;
-    if (sort_bits > 32) sort_bits = 32;
+    if (sort_bits > NM_ORDER_KEY_BITS) sort_bits = NM_ORDER_KEY_BITS;
     // the compact key always fits 32 bits (31 at 10 M points of the benchmark scene): the sort moves 8
     // bytes per pair and pass
     k_order_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, d_order_dev, key_tmp, val_tmp);
-    NM_HIP(ctx, rocprim::radix_sort_pairs<NmSortConfig>(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp, order,
+    NM_HIP(ctx, rocprim::radix_sort_pairs<NmSortConfig32>(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp, order,
                                           (size_t)n, 0, sort_bits, s));
     k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
     NM_HIP(ctx, hipGetLastError());
