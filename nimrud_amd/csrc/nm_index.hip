@@ -333,14 +333,19 @@ using NmSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim
                                                 rocprim::default_config, NM_MERGE_SORT_LIMIT>;
 // the spatial order's (key, row) pairs, both 32 bits: keys of NM_ORDER_KEY_BITS = 30 bits in THREE onesweep
 // passes of 10 bits.  (rocPRIM's tuned gfx950 entry for this type pair is 8 bits x 1024 threads x 16 items:
-// four passes, 0.655 ms for the order stage of the 10 M-point benchmark step; 10 bits x 1024 x 12: 0.545 ms.
-// 11 bits does not fit the rank kernel's LDS; blocks of 512 or 256 threads are slower at every item count.)
+// four passes, 0.655 ms for the order stage of the 10 M-point benchmark step; 10 bits x 1024 x 14: 0.53 ms
+// (8 items 0.575, 12 0.545, 13-15 0.53, 16 0.60).  11 bits does not fit the rank kernel's LDS; blocks of 512 or
+// 256 threads are slower at every item count; the histogram kernel is best left at 1024 x 16.)
 #ifndef NM_ONESWEEP_BITS
 #define NM_ONESWEEP_BITS 10
 #define NM_ONESWEEP_BLOCK 1024
-#define NM_ONESWEEP_ITEMS 12
+#define NM_ONESWEEP_ITEMS 14
 #endif
-using NmOnesweep32 = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>,
+#ifndef NM_HIST_BLOCK
+#define NM_HIST_BLOCK 1024
+#define NM_HIST_ITEMS 16
+#endif
+using NmOnesweep32 = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<NM_HIST_BLOCK, NM_HIST_ITEMS>,
                                                          rocprim::kernel_config<NM_ONESWEEP_BLOCK, NM_ONESWEEP_ITEMS>,
                                                          NM_ONESWEEP_BITS,
                                                          rocprim::block_radix_rank_algorithm::match>;
@@ -1432,7 +1437,10 @@ __global__ __launch_bounds__(256) void k_count_voxels_all(const ScaleDev* __rest
 
 int nm_index_clear_all(nm_ctx* ctx, const ScaleDev* d_ladder, int n, hipStream_t s)
 {
-    k_index_clear_all<<<dim3(1024, n), 256, 0, s>>>(d_ladder);
+#ifndef NM_CLEAR_BLOCKS
+#define NM_CLEAR_BLOCKS 1024
+#endif
+    k_index_clear_all<<<dim3(NM_CLEAR_BLOCKS, n), 256, 0, s>>>(d_ladder);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }
