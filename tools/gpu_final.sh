@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2_final4; mkdir -p $O
+O=gpurun_out/r2_final6; mkdir -p $O
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?"; tail -2 $O/smoke.log
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest exit $?" >> $O/pytest.log; tail -3 $O/pytest.log
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default exit $?"
