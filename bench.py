@@ -323,11 +323,17 @@ def main():
     # kernel tracks the shader clock, and a GPU that has idled through the CPU legs above needs a few hundred
     # milliseconds of load to settle (NIMRUD_BENCH_RUN_IN_S=0 switches it off)
     run_in = float(os.environ.get("NIMRUD_BENCH_RUN_IN_S", "0.5"))
-    t_in = time.perf_counter()
-    while run_in > 0 and time.perf_counter() - t_in < run_in:
-        for _ in range(4):
+    if world > 1:
+        # a step holds collectives: every rank must run the same number of them
+        for _ in range(32 if run_in > 0 else 0):
             step()
         torch.cuda.synchronize(dev)
+    else:
+        t_in = time.perf_counter()
+        while run_in > 0 and time.perf_counter() - t_in < run_in:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     fence()
