@@ -17,6 +17,8 @@ cd /tmp && export TMPDIR=/tmp
 trace() {   # name, command...
   local name=$1; shift
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$name" -- "$@" > "$OUT/trace_$name.out" 2> "$OUT/trace_$name.err" || echo "trace $name failed"
+  # gpurun copies back at most 64 MiB: the per-dispatch traces are large and only the stats are summarised
+  find "$OUT/trace_$name" -name "*_kernel_trace.csv" -delete
   echo "trace $name done"
 }
 trace c3 python3 "$R/bench.py" --steps 5 --warmup 2 --cpu-sample 0
