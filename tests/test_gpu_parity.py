@@ -663,6 +663,22 @@ def test_ladder_argument_checks():
     assert_features_close(got, oracle.process_fast(pts, pts, [0.1], [0.3]), pts)
 
 
+def test_bounds_pass_matches_numpy():
+    # nm_bounds (one atomic set per block) for sizes around the unrolled loop's tail and the grid's width; the
+    # ladder's own bounds pass (per-block extrema in the workspace, no atomics) is what every other test runs on
+    import ctypes
+    from nimrud_amd import device as nm_device
+    rt = _device_runtime()
+    rs = np.random.RandomState(4711)
+    for n in (1, 2, 63, 257, 1024 * 256 - 1, 1024 * 256 * 4 + 3, 1500001):
+        pts = rs.randn(n, 5) * np.array([3.0, 50.0, 0.01, 1.0, 1.0]) + np.array([1e5, -2e6, 0.5, 0.0, 0.0])
+        dev = torch.from_numpy(pts).cuda()
+        out = torch.empty(6, dtype=torch.float64, device="cuda")
+        rt.check(rt.lib.nm_bounds(rt.ctx, nm_device.ptr(dev), n, 5, nm_device.ptr(out), rt.stream()))
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:3], pts[:, :3].min(0)) and np.array_equal(got[3:], pts[:, :3].max(0))
+
+
 def test_device_built_lattices_match_the_hosts():
     # nm_ladder_features builds every lattice on the device (geometry.py:37-64: min - e/2, widths =
     # ceil(log2(span/e))); nm_multiscale_features takes them from the host, where numpy does that arithmetic.
