@@ -98,6 +98,18 @@ int nm_profile_end(nm_ctx* ctx, double* ms, int64_t* launches);
 int nm_bounds(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
               double* d_minmax, void* stream);
 
+/* ---- spatial order ------------------------------------------------------------------------------
+ * the order the ladder entry points work in internally (nm_order.hip), exposed for inspection and
+ * tests; no reference counterpart (the reference never reorders a cloud).  rows sorted by the
+ * compact Z-order key of their cell of `lat` (30 key bits, a wider key loses its low bits):
+ * d_order[i] = row of the point in sorted slot i, d_sorted_xyz (n,3) = the coordinates in that order,
+ * d_keys_sorted (nullable) = the key of every sorted slot.  radix sort of our own: three passes,
+ * per-tile digit counts + one flat scan + a scatter kernel per pass, no look-back.                 */
+size_t nm_spatial_order_workspace_bytes(int64_t n);
+int nm_spatial_order(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const nm_lattice* lat,
+                     uint32_t* d_order, double* d_sorted_xyz, uint32_t* d_keys_sorted, void* d_work,
+                     size_t work_bytes, void* stream);
+
 /* ---- voxelize -----------------------------------------------------------------------------------
  * VoxelFilter.coordinate_to_address + numpy.unique (geometry.py:103-116, 148-150): the sorted
  * distinct 64-bit voxel addresses x + (y << shifts[0]) + (z << shifts[1]) of the cells
@@ -293,10 +305,16 @@ int nm_halo_pack_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stri
  * *h_recv_rows / *h_sent_rows (HOST) the row counts, and d_global_minmax (device, 6 doubles) the extrema of
  * the WHOLE cloud, from which every rank builds the same lattices as a single-process run
  * (geometry.py:37).  traffic: all-gather of 6 doubles, (cell mode) all-gather of 256 KB, all-gather of
- * n_ranks + 2 int64, then grouped ncclSend / ncclRecv of 24-byte rows between the pairs that share a
+ * n_ranks + 3 int64, then grouped ncclSend / ncclRecv of 24-byte rows between the pairs that share a
  * boundary.  the call synchronises `stream` ONCE, to learn the sizes.  when some rank's buffers are too
  * small EVERY rank returns NM_ERR_WORKSPACE (with its own counts filled in) before anything is sent, so
- * the hosts can grow their buffers and call again.  the send staging area is whatever d_work holds beyond
+ * the hosts can grow their buffers and call again.  a tile may be EMPTY (n = 0: it contributes an empty
+ * box and receives nothing).  a rank that alone is unwell - a sticky failure of an earlier call, bad cloud
+ * arguments - still goes through the collectives, with an empty contribution and its status in the
+ * announced row: after the host synchronisation EVERY rank returns that status; nobody waits in an
+ * all-gather for a rank that has left.  (nm_halo_plan_from_matrix is that decision as a host function
+ * of the gathered matrix - n_ranks rows of n_ranks + 3 int64: rows sent to each rank, send capacity,
+ * receive capacity, status - exported so that it can be tested without a communicator.)  the send staging area is whatever d_work holds beyond
  * nm_halo_workspace_bytes(0, n_ranks).  NM_HALO_INCLUDE_SELF (or-ed into mode) makes a rank its own
  * neighbour as well - it then receives its own tile - which is how a one-rank communicator exercises the
  * whole path.  no reference counterpart: the reference is single-process.                              */
@@ -306,6 +324,8 @@ int nm_comm_unique_id(void* id_out /* NM_COMM_ID_BYTES, host */);
 int nm_comm_create(nm_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id, void** comm_out);
 int nm_comm_destroy(nm_ctx* ctx, void* comm);
 size_t nm_halo_workspace_bytes(int64_t send_capacity_rows, int32_t n_ranks);
+int nm_halo_plan_from_matrix(const int64_t* matrix, int32_t n_ranks, int32_t rank, int64_t* send_off,
+                             int64_t* recv_off, int64_t* sent_rows, int64_t* recv_rows, int32_t* culprit);
 int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t rank,
                      const double* d_xyz, int64_t n, int64_t stride, double margin, int32_t mode,
                      double* d_recv, int64_t recv_capacity_rows,

@@ -21,7 +21,7 @@ NM_ERR_RADIUS = -5
 NM_ERR_COMM = -6
 NM_COMM_ID_BYTES = 128
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i64 = ctypes.c_int64
 c_i32 = ctypes.c_int32
@@ -62,6 +62,9 @@ SIGNATURES = {
     "nm_set_normal_output": (ctypes.c_int, [c_ptr, c_ptr, ctypes.c_int64]),
     "nm_profile_end": (ctypes.c_int, [c_ptr, ctypes.POINTER(c_f64 * 4), ctypes.POINTER(c_i64)]),
     "nm_bounds": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "nm_spatial_order_workspace_bytes": (c_size, [c_i64]),
+    "nm_spatial_order": (ctypes.c_int,
+                         [c_ptr, c_ptr, c_i64, c_i64, _LATP, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "nm_voxelize_workspace_bytes": (c_size, [c_i64]),
     "nm_voxelize": (ctypes.c_int,
                     [c_ptr, c_ptr, c_i64, c_i64, _LATP, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
@@ -111,6 +114,10 @@ SIGNATURES = {
     "nm_comm_create": (ctypes.c_int, [c_ptr, c_i32, c_i32, c_ptr, ctypes.POINTER(c_ptr)]),
     "nm_comm_destroy": (ctypes.c_int, [c_ptr, c_ptr]),
     "nm_halo_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "nm_halo_plan_from_matrix": (ctypes.c_int,
+                                 [ctypes.POINTER(c_i64), c_i32, c_i32, ctypes.POINTER(c_i64),
+                                  ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
+                                  ctypes.POINTER(c_i32)]),
     "nm_halo_exchange": (ctypes.c_int,
                          [c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_i64, c_i64, c_f64, c_i32, c_ptr, c_i64,
                           ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, c_ptr, c_size, c_ptr]),
@@ -136,6 +143,11 @@ def load():
         raise ImportError(
             "libnimrud_hip.so is not built (expected at %s). build it with "
             "`make -C nimrud_amd/csrc`; nimrud_amd has no CPU fallback." % LIBRARY_PATH)
+    # torch first: the process must hold ONE HIP runtime, the one torch brings.  (loaded the other way round,
+    # this library pulls in /opt/rocm's libamdhip64 and torch then brings its own; on the pool's boxes the
+    # first one reports "no ROCm-capable device" - seen with `python __graft_entry__.py smoke`, which loads
+    # the library in build() before smoke() imports torch.)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIBRARY_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header and library out of sync

@@ -5,31 +5,45 @@
 
 #include "nm_common.h"
 
-extern "C" int nm_abi_version(void) { return 5; }
+extern "C" int nm_abi_version(void) { return 6; }
+
+// nm_create has no context to leave a message in yet: what failed goes to stderr
+#define NM_CREATE_TRY(call)                                                                       \
+    do {                                                                                          \
+        const hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess) {                                                                   \
+            fprintf(stderr, "nm_create: %s failed: %s\n", #call, hipGetErrorString(_e));          \
+            if (ctx) nm_destroy(ctx);                                                             \
+            return NM_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
 
 extern "C" int nm_create(nm_ctx** out, int device)
 {
     if (!out) return NM_ERR_INVALID;
     *out = nullptr;
+    nm_ctx* ctx = nullptr;
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return NM_ERR_HIP;
+    NM_CREATE_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) {
+        fprintf(stderr, "nm_create: device %d of %d\n", device, count);
+        return NM_ERR_HIP;
+    }
     // the caller's current device is left as it was (torch reads the same process-wide setting)
     nm_device_guard guard(device);
     int now = -1;
-    if (hipGetDevice(&now) != hipSuccess || now != device) return NM_ERR_HIP;
+    NM_CREATE_TRY(hipGetDevice(&now));
+    if (now != device) return NM_ERR_HIP;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return NM_ERR_HIP;
-    nm_ctx* ctx = new nm_ctx();
+    NM_CREATE_TRY(hipGetDeviceProperties(&prop, device));
+    ctx = new nm_ctx();
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
     // the sticky status words: the only memory the library owns (256 B on the device, 256 B pinned)
-    if (hipMalloc((void**)&ctx->d_status, NM_ST_WORDS * 4) != hipSuccess ||
-        hipMemset(ctx->d_status, 0, NM_ST_WORDS * 4) != hipSuccess ||
-        hipHostMalloc((void**)&ctx->h_status, NM_ST_WORDS * 4, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->status_event, hipEventDisableTiming) != hipSuccess) {
-        nm_destroy(ctx);
-        return NM_ERR_HIP;
-    }
+    NM_CREATE_TRY(hipMalloc((void**)&ctx->d_status, NM_ST_WORDS * 4));
+    NM_CREATE_TRY(hipMemset(ctx->d_status, 0, NM_ST_WORDS * 4));
+    NM_CREATE_TRY(hipHostMalloc((void**)&ctx->h_status, NM_ST_WORDS * 4, hipHostMallocDefault));
+    NM_CREATE_TRY(hipEventCreateWithFlags(&ctx->status_event, hipEventDisableTiming));
     for (int i = 0; i < NM_ST_WORDS; ++i) ctx->h_status[i] = 0u;
     *out = ctx;
     return NM_OK;

@@ -30,7 +30,8 @@ constexpr int NM_FUSED_FOREST_CLASSES = 8;
 
 // the classifier behind the last scale (nm_set_forest_output): 8-byte nodes, see nm_forest::d_packed8
 struct ForestDev {
-    const uint2* nodes;          // {fp32 threshold rounded down, packed}: bit 31 leaf; else left << 5 | feature
+    const uint2* nodes;          // {fp32 threshold rounded down, packed}: bit 31 leaf (row of its class distribution
+                                 // << 13); else left child << 13 | feature << 8 (ForestModel.pack_nodes8)
     const double* leaf_value;    // (n_leaves, n_classes), rows sum to 1
     const int32_t* roots;        // root node of each tree
     int32_t n_trees, n_classes, n_features;
@@ -255,9 +256,51 @@ struct OrderDev {
     LatticeDev L;            // the finest lattice of the ladder
     ZLayout Z;
     int32_t morton;          // 1: compact Z-order key, 0: superblock key (some width above 21 bits)
-    int32_t shift;           // low key bits dropped so that the key fits 32 bits
+    int32_t shift;           // low key bits dropped so that the key fits NM_ORDER_KEY_BITS
     int32_t valid;
+    int32_t bpp;             // key bits per radix pass: ceil(key bits / 3), at most NM_ORDER_PASS_BITS
 };
+
+// bits of the spatial order's sort key (a wider key loses its low bits): three radix passes of at most 10 bits.
+// (the benchmark scene's finest lattice has 31: the one bit makes no measurable difference to the index
+// build or the search; round 1 measured that six do)
+#ifndef NM_ORDER_KEY_BITS
+#define NM_ORDER_KEY_BITS 30
+#endif
+constexpr int NM_ORDER_PASS_BITS = 10;
+
+// the spatial order of a lattice: which key, how its bits are laid out, what is dropped to fit the sort key
+__host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O)
+{
+    O->L = L;
+    int wmax = L.wx > L.wy ? L.wx : L.wy;
+    if (L.wz > wmax) wmax = L.wz;
+    O->morton = wmax <= 21;
+    // axis roles in the compact Z-order key: the axis with the smallest width drops out of the 2-way
+    // zone; with ties the later axis is treated as the smaller one (it then simply has no bits there)
+    const int wd[3] = {L.wx, L.wy, L.wz};
+    int smallest = 0;
+    for (int a = 1; a < 3; ++a)
+        if (wd[a] <= wd[smallest]) smallest = a;
+    O->Z.w1 = wd[smallest];
+    O->Z.w2 = 64;
+    for (int a = 0, slot2 = 0; a < 3; ++a) {
+        if (a == smallest) {
+            O->Z.off2[a] = -1;
+        } else {
+            O->Z.off2[a] = slot2++;
+            if (wd[a] < O->Z.w2) O->Z.w2 = wd[a];
+        }
+    }
+    const int bits = O->morton ? L.wx + L.wy + L.wz : L.keybits;
+    O->shift = bits > NM_ORDER_KEY_BITS ? bits - NM_ORDER_KEY_BITS : 0;
+    const int kept = bits - O->shift;
+    int bpp = (kept + 2) / 3;
+    if (bpp < 1) bpp = 1;
+    if (bpp > NM_ORDER_PASS_BITS) bpp = NM_ORDER_PASS_BITS;
+    O->bpp = bpp;
+    O->valid = 1;
+}
 
 constexpr int NM_MAX_LADDER = 32;     // scales per ladder call
 #ifndef NM_DENSE_LOG2_VALUE
@@ -320,6 +363,16 @@ __device__ __forceinline__ uint64_t nm_cell_key(uint32_t cx, uint32_t cy, uint32
     uint64_t sb = nm_sb_key(cx >> NM_SBX_BITS, cy >> NM_SBY_BITS, cz >> NM_SBZ_BITS, L);
     uint32_t local = ((cz & 7u) << 8) | ((cy & 7u) << 5) | (cx & 31u);
     return (sb << NM_LOCAL_BITS) | local;
+}
+
+// XCD-aware block -> batch mapping: workgroups are dealt round-robin over the 8 XCDs, so give every
+// XCD one contiguous eighth of the batches; neighbouring batches then share that XCD's L2.  bijective for
+// any grid size.
+__device__ __forceinline__ int64_t nm_xcd_batch(int64_t b, int64_t nb)
+{
+    int64_t xcd = b & 7, q = nb >> 3, r = nb & 7;
+    int64_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
 }
 
 __device__ __forceinline__ uint32_t nm_hash64(uint64_t k)

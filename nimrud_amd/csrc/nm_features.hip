@@ -460,16 +460,6 @@ __device__ __forceinline__ void lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// XCD-aware block -> batch mapping: workgroups are dealt round-robin over the 8 XCDs, so give every
-// XCD one contiguous eighth of the sorted query order; neighbouring batches share leaves in that
-// XCD's L2.  bijective for any grid size.
-__device__ __forceinline__ int64_t nm_xcd_batch(int64_t b, int64_t nb)
-{
-    int64_t xcd = b & 7, q = nb >> 3, r = nb & 7;
-    int64_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (b >> 3);
-}
-
 // ---- static geometry of the candidate window ---------------------------------------------------------
 // whatever the position of a query inside its home cell, candidate (dx,dy,dz) (cell offsets) lies at a
 // distance between sqrt(sum max(|d|-1/2,0)^2) and sqrt(sum (|d|+1/2)^2) cells.  so for the row
@@ -729,12 +719,23 @@ __device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, const uin
                                                    float* xs, int lane, bool have, uint32_t qi)
 {
     const ForestDev& F = A.F;
+    bool undefined = false;      // a scale of this ladder had no addressable lattice: its columns are NaN
     if (have) {
         const double* row = A.feat + (int64_t)qi * A.fstride;
-        for (int f = 0; f < F.n_features; ++f) xs[f * 64 + lane] = (float)row[f];
+        for (int f = 0; f < F.n_features; ++f) {
+            const double v = row[f];
+            undefined = undefined || v != v;
+            xs[f * 64 + lane] = (float)v;
+        }
     }
     lds_fence();
     if (!have) return;
+    if (undefined) {
+        if (F.proba)
+            for (int c = 0; c < F.n_classes; ++c) F.proba[(int64_t)qi * F.pstride + c] = __builtin_nan("");
+        if (F.label) F.label[qi] = -1;
+        return;
+    }
     const uint32_t lane4 = (uint32_t)lane * 4u;
     const char* xsb = (const char*)xs;
     double acc[NM_FUSED_FOREST_CLASSES];
@@ -937,7 +938,15 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     // (the scale array is a kernel parameter of its own, restrict-qualified: the compiler can then prove
     // that nothing in the kernel writes it and reads it with scalar loads into SGPRs)
     const ScaleDev* __restrict__ S = scales + s;
-    if (!S->valid) continue;                 // reported through the context's status words
+    if (!S->valid) {
+        // a lattice that cannot be addressed: reported through the context's status words at the caller's next
+        // synchronisation point; until then its columns hold NaN, never stale memory that looks like features
+        if (have) {
+            double* o = nm_row_ptr(A.feat, qi, A.fstride, 4 * s);
+            o[0] = o[1] = o[2] = o[3] = __builtin_nan("");
+        }
+        continue;
+    }
     const LatticeDev L = S->L;
     const IndexDev I = S->I;
     const double r2 = S->r2;
@@ -1321,7 +1330,14 @@ __global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
         }
         for (int32_t s = A.s_begin; s < A.s_end; ++s) {
             const ScaleDev* __restrict__ S = A.scales + s;
-            if (!S->valid || (ONLY_UNPRUNED && S->prune_ok)) continue;
+            if (!S->valid) {
+                if (!ONLY_UNPRUNED && have) {      // (with a table kernel behind it, that kernel writes the NaNs)
+                    double* o = A.feat + (int64_t)qi * A.fstride + 4 * s;
+                    o[0] = o[1] = o[2] = o[3] = __builtin_nan("");
+                }
+                continue;
+            }
+            if (ONLY_UNPRUNED && S->prune_ok) continue;
             bool sp = false;
             if (have) nm_lane_generic(A, S->L, S->I, S->r2, s, qi, qx, qy, qz, &sp);
             if (A.sparse) {
@@ -1826,10 +1842,10 @@ extern "C" int nm_scale_features(nm_ctx* ctx, const double* d_query, int64_t n_q
 // needs (min(superblocks of the lattice, points) leaves).
 
 struct LadderLayout {
-    // per cloud: sort scratch, the order and the coordinates in that order
-    size_t s_key_tmp, s_val_tmp, s_key, s_order, s_xyz;
-    size_t q_key_tmp, q_val_tmp, q_key, q_order, q_xyz;
-    size_t sort_temp, sort_temp_bytes;
+    // per cloud: the order and the coordinates in that order
+    size_t s_order, s_xyz;
+    size_t q_order, q_xyz;
+    size_t order_scratch, order_scratch_bytes;     // the spatial sort's keys, pair buffers and count matrix
     size_t minmax;                   // 6 doubles: the search cloud's extrema
     size_t bounds_scratch;           // the bounds pass's per-block extrema
     size_t ladder;                   // ScaleDev[n_scales]
@@ -1848,22 +1864,16 @@ static void ladder_layout(int64_t nq, int64_t ns, int n_scales, bool shared, boo
         off += align_up(bytes);
         return at;
     };
-    S->s_key_tmp = take((size_t)ns * 4);
-    S->s_val_tmp = take((size_t)ns * 4);
-    S->s_key = take((size_t)ns * 4);
     S->s_order = take((size_t)ns * 4);
     S->s_xyz = take((size_t)ns * 24);
     if (!shared) {
-        S->q_key_tmp = take((size_t)nq * 4);
-        S->q_val_tmp = take((size_t)nq * 4);
-        S->q_key = take((size_t)nq * 4);
         S->q_order = take((size_t)nq * 4);
         S->q_xyz = take((size_t)nq * 24);
     } else {
-        S->q_key_tmp = S->q_val_tmp = S->q_key = S->q_order = S->q_xyz = 0;
+        S->q_order = S->q_xyz = 0;
     }
-    S->sort_temp_bytes = nm_sort_pairs_temp_bytes(ns > nq ? ns : nq);
-    S->sort_temp = take(S->sort_temp_bytes);
+    S->order_scratch_bytes = nm_order_scratch_bytes(ns > nq ? ns : nq);
+    S->order_scratch = take(S->order_scratch_bytes);
     S->minmax = take(64);
     S->bounds_scratch = take(NM_BOUNDS_SCRATCH_BYTES);
     S->ladder = take(sizeof(ScaleDev) * (size_t)NM_MAX_LADDER);
@@ -1905,7 +1915,6 @@ struct LadderCall {
     const double* d_search; int64_t n_search, search_stride;
     const double* edges; const double* radii; int32_t n_scales;
     double* d_feat; int64_t feat_stride; int64_t* d_info;
-    unsigned sort_bits;
 };
 
 static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, char* w, bool shared,
@@ -1913,18 +1922,14 @@ static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, c
 {
     const ScaleDev* d_ladder = (const ScaleDev*)(w + S.ladder);
     const OrderDev* d_order = (const OrderDev*)(w + S.order_dev);
-    int rc = nm_order_build(ctx, C.d_search, C.n_search, C.search_stride, d_order, C.sort_bits,
-                            (uint32_t*)(w + S.s_key_tmp), (uint32_t*)(w + S.s_val_tmp),
-                            (uint32_t*)(w + S.s_key), (uint32_t*)(w + S.s_order), w + S.sort_temp,
-                            S.sort_temp_bytes, (double*)(w + S.s_xyz), s);
+    int rc = nm_order_build(ctx, C.d_search, C.n_search, C.search_stride, d_order, w + S.order_scratch,
+                            S.order_scratch_bytes, (uint32_t*)(w + S.s_order), (double*)(w + S.s_xyz), s);
     if (rc) return rc;
     const uint32_t* q_order = (const uint32_t*)(w + S.s_order);
     const double* q_xyz = (const double*)(w + S.s_xyz);
     if (!shared && C.n_query > 0) {
-        rc = nm_order_build(ctx, C.d_query, C.n_query, C.query_stride, d_order, C.sort_bits,
-                            (uint32_t*)(w + S.q_key_tmp), (uint32_t*)(w + S.q_val_tmp),
-                            (uint32_t*)(w + S.q_key), (uint32_t*)(w + S.q_order), w + S.sort_temp,
-                            S.sort_temp_bytes, (double*)(w + S.q_xyz), s);
+        rc = nm_order_build(ctx, C.d_query, C.n_query, C.query_stride, d_order, w + S.order_scratch,
+                            S.order_scratch_bytes, (uint32_t*)(w + S.q_order), (double*)(w + S.q_xyz), s);
         if (rc) return rc;
         q_order = (const uint32_t*)(w + S.q_order);
         q_xyz = (const double*)(w + S.q_xyz);
@@ -2089,12 +2094,8 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
     rc = nm_ladder_put(ctx, L, I, radii, n_scales, finest, S.leaf_capacity, (ScaleDev*)(w + S.ladder),
                        (OrderDev*)(w + S.order_dev), s);
     if (rc) return rc;
-    const LatticeDev& Lf = L[finest];
-    int wmax = Lf.wx > Lf.wy ? Lf.wx : Lf.wy;
-    if (Lf.wz > wmax) wmax = Lf.wz;
-    const int key_bits = wmax <= 21 ? Lf.wx + Lf.wy + Lf.wz : Lf.keybits;
     LadderCall C{d_query, n_query, query_stride, d_search, n_search, search_stride, edges, radii,
-                 n_scales, d_feat, feat_stride, d_info, (unsigned)(key_bits > 32 ? 32 : key_bits)};
+                 n_scales, d_feat, feat_stride, d_info};
     return run_ladder(ctx, C, S, w, shared, s);
 }
 
@@ -2128,12 +2129,12 @@ extern "C" int nm_ladder_features(nm_ctx* ctx, const double* d_query, int64_t n_
     nm_profile_mark(ctx, s);
     // the search cloud's extrema never leave the device: bounds pass (unless the caller has them, e.g. the
     // global extrema of a multi-GPU job), then one tiny kernel turns them into every scale's lattice
-    const double* mm = d_minmax;
-    if (!mm) {
-        rc = nm_bounds_scratch(ctx, d_search, n_search, search_stride, (double*)(w + S.minmax),
-                               w + S.bounds_scratch, s);
+    const void* partial = nullptr;
+    int bounds_blocks = 0;
+    if (!d_minmax) {
+        rc = nm_bounds_partial(ctx, d_search, n_search, search_stride, w + S.bounds_scratch, &bounds_blocks, s);
         if (rc) return rc;
-        mm = (const double*)(w + S.minmax);
+        partial = w + S.bounds_scratch;
     }
     void* hash[NM_MAX_LADDER];
     void* leaf[NM_MAX_LADDER];
@@ -2143,11 +2144,12 @@ extern "C" int nm_ladder_features(nm_ctx* ctx, const double* d_query, int64_t n_
         leaf[i] = w + S.leaf[i];
         counters[i] = w + S.counters[i];
     }
-    rc = nm_ladder_make(ctx, mm, edges, radii, n_scales, finest, hash, leaf, counters, S.hash_capacity,
-                        S.leaf_capacity, (ScaleDev*)(w + S.ladder), (OrderDev*)(w + S.order_dev), s);
+    rc = nm_ladder_make(ctx, d_minmax, partial, bounds_blocks, (double*)(w + S.minmax), edges, radii, n_scales,
+                        finest, hash, leaf, counters, S.hash_capacity, S.leaf_capacity,
+                        (ScaleDev*)(w + S.ladder), (OrderDev*)(w + S.order_dev), s);
     if (rc) return rc;
     LadderCall C{d_query, n_query, query_stride, d_search, n_search, search_stride, edges, radii,
-                 n_scales, d_feat, feat_stride, d_info, 32u};
+                 n_scales, d_feat, feat_stride, d_info};
     return run_ladder(ctx, C, S, w, shared, s);
 }
 

@@ -21,6 +21,7 @@
 // link; nothing is reduced, so ring bandwidth never enters).
 
 #include "nm_common.h"
+#include "nm_index.h"
 
 #include <string.h>
 
@@ -434,8 +435,8 @@ static void halo_layout(int32_t n_ranks, HaloLayout* H)
     H->local = take(6 * 8);
     H->boxes = take((size_t)n_ranks * 6 * 8);
     H->global = take(6 * 8);
-    H->counts = take((size_t)(n_ranks + 2) * 8);
-    H->matrix = take((size_t)n_ranks * (n_ranks + 2) * 8);
+    H->counts = take((size_t)(n_ranks + 3) * 8);
+    H->matrix = take((size_t)n_ranks * (n_ranks + 3) * 8);
     H->offsets = take((size_t)n_ranks * 8);
     H->cursor = take((size_t)n_ranks * 8);
     H->cellset_work = take(nm_halo_cellset_workspace_bytes());
@@ -460,14 +461,70 @@ __global__ void k_put_offsets(OffsetList L, int32_t n, int64_t* __restrict__ out
 {
     if ((int)threadIdx.x < n) out[threadIdx.x] = L.v[threadIdx.x];
 }
-// what every rank tells every other: its pair counts and how much it can send and receive
+// what every rank tells every other: its pair counts, how much it can send and receive, and whether it is well
 __global__ void k_halo_announce(int64_t* __restrict__ counts, int32_t n_ranks, int64_t send_capacity,
-                                int64_t recv_capacity)
+                                int64_t recv_capacity, int64_t status)
 {
     if (threadIdx.x == 0) {
         counts[n_ranks] = send_capacity;
         counts[n_ranks + 1] = recv_capacity;
+        counts[n_ranks + 2] = status;
     }
+}
+
+// the contribution of a rank that has nothing to contribute (an empty tile, or a rank that must fail): an empty
+// box, an empty cell set, no rows for anybody
+__global__ void k_halo_nothing(double* __restrict__ local, uint32_t* __restrict__ own_cells, int32_t words,
+                               int64_t* __restrict__ counts, int32_t n_ranks)
+{
+    for (int t = threadIdx.x; t < words; t += blockDim.x) own_cells[t] = 0u;
+    if (threadIdx.x < 6) local[threadIdx.x] = threadIdx.x < 3 ? INFINITY : -INFINITY;
+    if ((int)threadIdx.x < n_ranks) counts[threadIdx.x] = 0;
+}
+
+// the host side of step 3, on a count matrix every rank holds identically (row r: rows r sends to each rank,
+// then r's send capacity, receive capacity and status word).  fills this rank's offsets and totals and returns
+// the verdict - NM_OK, NM_ERR_WORKSPACE with the first rank that is short of room, or the first unwell rank's
+// status - which is therefore the SAME on every rank: either all go on to the exchange or none does.
+// (a function of its own so that the CPU tests can drive it with synthetic matrices: tests/test_abi_and_host.py)
+extern "C" int nm_halo_plan_from_matrix(const int64_t* matrix, int32_t n_ranks, int32_t rank,
+                                        int64_t* send_off, int64_t* recv_off, int64_t* sent_rows,
+                                        int64_t* recv_rows, int32_t* culprit)
+{
+    if (!matrix || n_ranks < 1 || rank < 0 || rank >= n_ranks || !send_off || !recv_off || !sent_rows ||
+        !recv_rows)
+        return NM_ERR_INVALID;
+    const int row = n_ranks + 3;
+    auto pair = [&](int from, int to) { return matrix[(size_t)from * row + to]; };
+    int64_t sent = 0, received = 0;
+    for (int j = 0; j < n_ranks; ++j) {
+        send_off[j] = sent;
+        recv_off[j] = received;
+        sent += pair(rank, j);
+        received += pair(j, rank);
+    }
+    *sent_rows = sent;
+    *recv_rows = received;
+    if (culprit) *culprit = -1;
+    for (int r = 0; r < n_ranks; ++r) {
+        const int64_t st = matrix[(size_t)r * row + n_ranks + 2];
+        if (st != 0) {
+            if (culprit) *culprit = r;
+            return (int)st;
+        }
+    }
+    for (int r = 0; r < n_ranks; ++r) {
+        int64_t out_r = 0, in_r = 0;
+        for (int j = 0; j < n_ranks; ++j) {
+            out_r += pair(r, j);
+            in_r += pair(j, r);
+        }
+        if (out_r > matrix[(size_t)r * row + n_ranks] || in_r > matrix[(size_t)r * row + n_ranks + 1]) {
+            if (culprit) *culprit = r;
+            return NM_ERR_WORKSPACE;
+        }
+    }
+    return NM_OK;
 }
 
 extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t rank,
@@ -476,13 +533,17 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
                                 int64_t* h_recv_rows, int64_t* h_sent_rows, double* d_global_minmax,
                                 void* d_work, size_t work_bytes, void* stream)
 {
-    NM_ENTER_STREAM(ctx, stream);
+    // this call holds collectives: whatever is wrong with THIS rank alone - a sticky failure of an earlier call,
+    // bad cloud arguments - must not make it leave while the others wait in an all-gather.  such a rank goes
+    // through the collectives with an empty contribution and a status word that makes every rank return that
+    // status after the one host synchronisation.  only what makes the collectives themselves impossible (no
+    // communicator, no workspace for the fixed part, a wrong rank count) returns at once.
+    if (!ctx) return NM_ERR_INVALID;
+    nm_device_guard _nm_guard(ctx->device);
     const bool include_self = (mode & NM_HALO_INCLUDE_SELF) != 0;
     mode &= ~NM_HALO_INCLUDE_SELF;
-    if (!nccl_comm || n_ranks < 1 || n_ranks > NM_MAX_BOXES || rank < 0 || rank >= n_ranks ||
-        !d_xyz || n < 1 || stride < 3 || !(margin > 0.0) ||
-        (mode != NM_HALO_BOXES && mode != NM_HALO_CELLS) || recv_capacity_rows < 0 ||
-        (recv_capacity_rows > 0 && !d_recv) || !h_recv_rows || !h_sent_rows || !d_work)
+    if (!nccl_comm || n_ranks < 1 || n_ranks > NM_MAX_BOXES || rank < 0 || rank >= n_ranks || !h_recv_rows ||
+        !h_sent_rows || !d_work)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_halo_exchange: bad arguments");
     HaloLayout H;
     halo_layout(n_ranks, &H);
@@ -495,6 +556,15 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
     if (count != n_ranks)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_halo_exchange: communicator has %d ranks, not %d", count,
                 n_ranks);
+    int local_status = nm_capturing((hipStream_t)stream) ? NM_OK : nm_status_poll(ctx, false);
+    if (local_status == NM_OK &&
+        (n < 0 || (n > 0 && (!d_xyz || stride < 3)) || !(margin > 0.0) ||
+         (mode != NM_HALO_BOXES && mode != NM_HALO_CELLS) || recv_capacity_rows < 0 ||
+         (recv_capacity_rows > 0 && !d_recv))) {
+        ctx->error = "nm_halo_exchange: bad arguments";
+        local_status = NM_ERR_INVALID;
+    }
+    const bool contribute = local_status == NM_OK && n > 0;       // an empty tile is a legitimate input
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)d_work;
     double* local = (double*)(w + H.local);
@@ -509,60 +579,64 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
     double* send = (double*)(w + H.send);
     const int64_t send_capacity = (int64_t)((work_bytes - H.total_fixed) / 24);
     const int32_t skip = include_self ? -1 : rank;
-    const int row = n_ranks + 2;        // entries every rank announces
+    const int row = n_ranks + 3;        // entries every rank announces
 
     // 1. every tile's box; their extrema are the global extrema (geometry.py:37 needs the GLOBAL minimum)
-    int rc = nm_bounds(ctx, d_xyz, n, stride, local, stream);
-    if (rc) return rc;
+    int rc = NM_OK;
+    if (contribute) {
+        rc = nm_bounds_scratch(ctx, d_xyz, n, stride, local, nullptr, s);
+        if (rc) return rc;
+    } else {
+        k_halo_nothing<<<1, 256, 0, s>>>(local, own_cells, NM_CELLSET_WORDS, counts, n_ranks);
+    }
     NM_NCCL(ctx, ncclAllGather(local, boxes, 6, ncclDouble, comm, s));
     k_halo_boxes<<<1, 64, 0, s>>>(boxes, n_ranks, margin, global, d_global_minmax);
     // 2. who needs which of my points
     DestSet B{boxes, nullptr, nullptr, 0.0, n_ranks, skip};
     if (mode == NM_HALO_CELLS) {
-        rc = nm_halo_cellset(ctx, d_xyz, n, stride, global, margin, own_cells, w + H.cellset_work,
-                             nm_halo_cellset_workspace_bytes(), stream);
-        if (rc) return rc;
+        if (contribute) {
+            rc = nm_halo_cellset(ctx, d_xyz, n, stride, global, margin, own_cells, w + H.cellset_work,
+                                 nm_halo_cellset_workspace_bytes(), stream);
+            if (rc) return rc;
+        }
         NM_NCCL(ctx, ncclAllGather(own_cells, cellsets, NM_CELLSET_WORDS, ncclUint32, comm, s));
         B = DestSet{nullptr, cellsets, global, margin, n_ranks, skip};
     }
-    rc = halo_count(ctx, d_xyz, n, stride, B, counts, s);
-    if (rc) return rc;
-    k_halo_announce<<<1, 64, 0, s>>>(counts, n_ranks, send_capacity, recv_capacity_rows);
-    // 3. everybody learns every pair count and every capacity; the one host synchronisation
+    if (contribute) {
+        rc = halo_count(ctx, d_xyz, n, stride, B, counts, s);
+        if (rc) return rc;
+    }
+    k_halo_announce<<<1, 64, 0, s>>>(counts, n_ranks, send_capacity, recv_capacity_rows, (int64_t)local_status);
+    // 3. everybody learns every pair count, every capacity and every status; the one host synchronisation
     NM_NCCL(ctx, ncclAllGather(counts, matrix, (size_t)row, ncclInt64, comm, s));
     std::vector<int64_t> host((size_t)n_ranks * row);
     NM_HIP(ctx, hipMemcpyAsync(host.data(), matrix, host.size() * 8, hipMemcpyDeviceToHost, s));
     NM_HIP(ctx, hipStreamSynchronize(s));
     auto pair = [&](int from, int to) { return host[(size_t)from * row + to]; };
-    int64_t sent = 0, received = 0;
     OffsetList send_off, recv_off;
-    for (int j = 0; j < n_ranks; ++j) {
-        send_off.v[j] = sent;
-        recv_off.v[j] = received;
-        sent += pair(rank, j);
-        received += pair(j, rank);
-    }
-    *h_sent_rows = sent;
-    *h_recv_rows = received;
+    int32_t culprit = -1;
     // the matrix is the same on every rank, so either every rank returns here or none does: nobody is
     // left waiting in the exchange for a rank that has given up
-    for (int r = 0; r < n_ranks; ++r) {
-        int64_t out_r = 0, in_r = 0;
-        for (int j = 0; j < n_ranks; ++j) {
-            out_r += pair(r, j);
-            in_r += pair(j, r);
-        }
-        if (out_r > host[(size_t)r * row + n_ranks] || in_r > host[(size_t)r * row + n_ranks + 1])
-            NM_FAIL(ctx, NM_ERR_WORKSPACE,
-                    "nm_halo_exchange: rank %d has to send %lld and receive %lld rows but has room for "
-                    "%lld and %lld; this rank sends %lld and receives %lld", r, (long long)out_r,
-                    (long long)in_r, (long long)host[(size_t)r * row + n_ranks],
-                    (long long)host[(size_t)r * row + n_ranks + 1], (long long)sent, (long long)received);
+    const int verdict = nm_halo_plan_from_matrix(host.data(), n_ranks, rank, send_off.v, recv_off.v, h_sent_rows,
+                                                 h_recv_rows, &culprit);
+    if (verdict == NM_ERR_WORKSPACE)
+        NM_FAIL(ctx, NM_ERR_WORKSPACE,
+                "nm_halo_exchange: rank %d is short of room (it can send %lld and receive %lld rows); this rank "
+                "sends %lld and receives %lld", culprit, (long long)host[(size_t)culprit * row + n_ranks],
+                (long long)host[(size_t)culprit * row + n_ranks + 1], (long long)*h_sent_rows,
+                (long long)*h_recv_rows);
+    if (verdict != NM_OK) {
+        if (culprit != rank)
+            NM_FAIL(ctx, verdict, "nm_halo_exchange: rank %d reported status %d; nothing was exchanged", culprit,
+                    verdict);
+        return verdict;       // this rank's own failure: ctx->error already says what
     }
     // 4. pack and exchange: grouped point-to-point, one send and one receive per neighbour
-    k_put_offsets<<<1, 64, 0, s>>>(send_off, n_ranks, offsets);
-    rc = halo_pack(ctx, d_xyz, n, stride, B, offsets, cursor, send, s);
-    if (rc) return rc;
+    if (contribute) {
+        k_put_offsets<<<1, 64, 0, s>>>(send_off, n_ranks, offsets);
+        rc = halo_pack(ctx, d_xyz, n, stride, B, offsets, cursor, send, s);
+        if (rc) return rc;
+    }
     NM_NCCL(ctx, ncclGroupStart());
     for (int j = 0; j < n_ranks; ++j) {
         const int64_t to = pair(rank, j), from = pair(j, rank);

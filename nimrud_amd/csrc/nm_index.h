@@ -21,19 +21,11 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
                    void* index_mem, IndexDev* out, hipStream_t s);
 
 // whole-ladder path: one spatial order for all scales, every scale described by a ScaleDev in device memory.
-// order[i] = original row of sorted slot i (sorted by the compact 32-bit cell key of the lattice in
-// *d_order_dev), sorted_xyz = the coordinates in that order, (n,3) contiguous.
-int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
-                   const OrderDev* d_order_dev, unsigned sort_bits, uint32_t* key_tmp,
-                   uint32_t* val_tmp, uint32_t* key_sorted, uint32_t* order, void* sort_temp,
-                   size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s);
-
-// bits of the spatial order's sort key (a wider key loses its low bits): three radix passes of 10 bits.
-// (the benchmark scene's finest lattice has 31: the one bit makes no measurable difference to the index
-// build or the search; round 1 measured that six do)
-#ifndef NM_ORDER_KEY_BITS
-#define NM_ORDER_KEY_BITS 30
-#endif
+// order[i] = original row of sorted slot i (sorted by the compact cell key of the lattice in *d_order_dev,
+// nm_order.hip), sorted_xyz = the coordinates in that order, (n,3) contiguous.  scratch: nm_order_scratch_bytes(n)
+size_t nm_order_scratch_bytes(int64_t n);
+int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const OrderDev* d_order_dev,
+                   void* scratch, size_t scratch_bytes, uint32_t* order, double* sorted_xyz, hipStream_t s);
 
 // the extrema of a cloud (nm_bounds) with NM_BOUNDS_SCRATCH_BYTES of caller scratch: no atomics
 constexpr size_t NM_BOUNDS_SCRATCH_BYTES = 1024 * 6 * 8;
@@ -45,10 +37,15 @@ int nm_bounds_scratch(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t strid
 // 0: keep every index exactly as the host sized it (the one-scale path)
 int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const double* radii, int n_scales,
                   int finest, uint32_t leaf_alloc, ScaleDev* d_ladder, OrderDev* d_order, hipStream_t s);
-int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const double* edges, const double* radii,
+// d_bounds_partial set: the extrema are the bounds pass's per-block pieces (nm_bounds_partial); the ladder kernel
+// folds them and stores the six doubles in d_minmax_out.  else d_minmax holds them already
+int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const void* d_bounds_partial, int bounds_blocks,
+                   double* d_minmax_out, const double* edges, const double* radii,
                    int n_scales, int finest, void* const* hash, void* const* leaf, void* const* counters,
                    uint32_t hash_capacity, uint32_t leaf_capacity, ScaleDev* d_ladder, OrderDev* d_order,
                    hipStream_t s);
+int nm_bounds_partial(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, void* d_partial,
+                      int* blocks_out, hipStream_t s);
 
 // ---- the ladder's indexes: one per scale, cleared, built and counted together ---------------------------
 IndexDev nm_index_at(nm_ctx* ctx, void* index_mem, const IndexLayout& lay);

@@ -163,6 +163,19 @@ int nm_bounds_scratch(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t strid
     return NM_OK;
 }
 
+// the bounds pass alone: per-block extrema into `d_partial` (NM_BOUNDS_SCRATCH_BYTES); returns the number of
+// blocks that wrote one.  whoever reads them folds them (k_make_ladder)
+int nm_bounds_partial(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, void* d_partial,
+                      int* blocks_out, hipStream_t s)
+{
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > NM_BOUNDS_BLOCKS) blocks = NM_BOUNDS_BLOCKS;
+    k_bounds<<<(int)blocks, 256, 0, s>>>(d_xyz, n, stride, nullptr, (uint64_t*)d_partial);
+    NM_HIP(ctx, hipGetLastError());
+    *blocks_out = (int)blocks;
+    return NM_OK;
+}
+
 extern "C" int nm_bounds(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
                          double* d_minmax, void* stream)
 {
@@ -664,19 +677,6 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
 //   k_count_voxels_all   M = set bits of the allocated leaves, all scales of a ladder in one launch
 // ---------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_gather_xyz(const double* __restrict__ xyz, int64_t n,
-                                                    int64_t stride,
-                                                    const uint32_t* __restrict__ order,
-                                                    double* __restrict__ out)
-{
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double* p = xyz + (int64_t)order[i] * stride;
-    out[i * 3 + 0] = p[0];
-    out[i * 3 + 1] = p[1];
-    out[i * 3 + 2] = p[2];
-}
-
 __device__ __forceinline__ uint64_t nm_point_key(const double* __restrict__ p, const LatticeDev& L)
 {
     int32_t cx = nm_clamp_cell(nm_cell_fast(p[0], L.min_x, L.edge, L.inv_edge));
@@ -1026,128 +1026,6 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
     }
 }
 
-// 3-D Morton (Z-order) code of a cell, 21 bits per axis.  used only for the one-time spatial sort of the
-// whole-ladder path: a Z-order run of points is compact in all three axes at EVERY coarser scale,
-// which keeps the boxes the search kernel stages small (a column-major order scatters vertical
-// structures - poles, facades - over the whole slab).
-__device__ __forceinline__ uint64_t nm_spread3(uint32_t v)
-{
-    uint64_t x = v & 0x1FFFFFu;
-    x = (x | (x << 32)) & 0x001F00000000FFFFull;
-    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
-    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
-    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
-    x = (x | (x << 2)) & 0x1249249249249249ull;
-    return x;
-}
-
-// 2-way Morton spread of up to 21 bits
-__device__ __forceinline__ uint64_t nm_spread2(uint32_t v)
-{
-    uint64_t x = v;
-    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    x = (x | (x << 2)) & 0x3333333333333333ull;
-    x = (x | (x << 1)) & 0x5555555555555555ull;
-    return x;
-}
-
-// (measured in round 1: dropping 2 key bits per axis saves a radix pass but costs more in the index build and
-// the search kernel)
-
-__global__ __launch_bounds__(256) void k_order_keys(const double* __restrict__ xyz, int64_t n,
-                                                    int64_t stride,
-                                                    const OrderDev* __restrict__ order_dev,
-                                                    uint32_t* __restrict__ key,
-                                                    uint32_t* __restrict__ val)
-{
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const OrderDev& O = *order_dev;
-    uint64_t k = 0ull;
-    if (O.valid) {
-        const LatticeDev& L = O.L;
-        const ZLayout& Z = O.Z;
-        const double* p = xyz + i * stride;
-        int32_t cx = nm_clamp_cell(nm_cell_f(p[0], L.min_x, L.edge));
-        int32_t cy = nm_clamp_cell(nm_cell_f(p[1], L.min_y, L.edge));
-        int32_t cz = nm_clamp_cell(nm_cell_f(p[2], L.min_z, L.edge));
-        cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
-        cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
-        cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
-        if (O.morton) {
-            // Z-order with the always-zero bits squeezed out: bit b of every axis that HAS a bit b, lowest
-            // bits first - same order as the plain 3-way interleave, but only wx+wy+wz key bits to sort.
-            // with w1 <= w2 the two smaller widths: bits below w1 are interleaved 3-way, bits in [w1, w2)
-            // 2-way among the axes that still have bits, the rest belongs to the widest axis alone.
-            const uint32_t c[3] = {(uint32_t)cx, (uint32_t)cy, (uint32_t)cz};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const uint32_t lo = c[a] & ((1u << Z.w1) - 1u);
-                k |= nm_spread3(lo) << a;
-                if (Z.off2[a] >= 0) {
-                    const uint32_t mid = (c[a] >> Z.w1) & ((1u << (Z.w2 - Z.w1)) - 1u);
-                    k |= nm_spread2(mid) << (3 * Z.w1 + Z.off2[a]);
-                    k |= (uint64_t)(c[a] >> Z.w2) << (3 * Z.w1 + 2 * (Z.w2 - Z.w1));
-                }
-            }
-        } else {
-            k = nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
-        }
-        // the order only has to be spatially coherent: a key wider than NM_ORDER_KEY_BITS loses its low bits (the
-        // points of a small block of finest cells then stay in input order)
-        k >>= O.shift;
-    }
-    key[i] = (uint32_t)k;
-    val[i] = (uint32_t)i;
-}
-
-// the spatial order of a lattice: which key, how its bits are laid out, what is dropped to fit the sort key
-__host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O)
-{
-    O->L = L;
-    int wmax = L.wx > L.wy ? L.wx : L.wy;
-    if (L.wz > wmax) wmax = L.wz;
-    O->morton = wmax <= 21;
-    // axis roles in the compact Z-order key: the axis with the smallest width drops out of the 2-way
-    // zone; with ties the later axis is treated as the smaller one (it then simply has no bits there)
-    const int wd[3] = {L.wx, L.wy, L.wz};
-    int smallest = 0;
-    for (int a = 1; a < 3; ++a)
-        if (wd[a] <= wd[smallest]) smallest = a;
-    O->Z.w1 = wd[smallest];
-    O->Z.w2 = 64;
-    for (int a = 0, slot2 = 0; a < 3; ++a) {
-        if (a == smallest) {
-            O->Z.off2[a] = -1;
-        } else {
-            O->Z.off2[a] = slot2++;
-            if (wd[a] < O->Z.w2) O->Z.w2 = wd[a];
-        }
-    }
-    const int bits = O->morton ? L.wx + L.wy + L.wz : L.keybits;
-    O->shift = bits > NM_ORDER_KEY_BITS ? bits - NM_ORDER_KEY_BITS : 0;
-    O->valid = 1;
-}
-
-int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
-                   const OrderDev* d_order_dev, unsigned sort_bits, uint32_t* key_tmp,
-                   uint32_t* val_tmp, uint32_t* key_sorted, uint32_t* order, void* sort_temp,
-                   size_t sort_temp_bytes, double* sorted_xyz, hipStream_t s)
-{
-    if (sort_bits < 1) sort_bits = 1;
-    if (sort_bits > NM_ORDER_KEY_BITS) sort_bits = NM_ORDER_KEY_BITS;
-    // the compact key always fits 32 bits (31 at 10 M points of the benchmark scene): the sort moves 8
-    // bytes per pair and pass
-    k_order_keys<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, d_order_dev, key_tmp, val_tmp);
-    NM_HIP(ctx, rocprim::radix_sort_pairs<NmSortConfig32>(sort_temp, sort_temp_bytes, key_tmp, key_sorted, val_tmp, order,
-                                          (size_t)n, 0, sort_bits, s));
-    k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
-    NM_HIP(ctx, hipGetLastError());
-    return NM_OK;
-}
-
 // ---- the ladder in device memory ------------------------------------------------------------------------
 // scalar lattice parameters of VoxelFilter.__init__ / _calculate_shift (geometry.py:37-64) on the device:
 //   min_corner = min - e/2, max_corner = max + e/2                       geometry.py:37-38
@@ -1222,10 +1100,51 @@ __device__ inline void nm_scale_finish(ScaleDev* S, double radius, uint32_t hash
 }
 
 // from the cloud's extrema (6 doubles on the device) to every scale's lattice.  one thread per scale.
-__global__ void k_make_ladder(const double* __restrict__ minmax, LadderSpec P, ScaleDev* __restrict__ ladder,
-                              OrderDev* __restrict__ order_dev, uint32_t* __restrict__ status)
+// `partial` set: the extrema are still the per-block pieces of the bounds pass (k_bounds); this kernel folds
+// them first (what k_bounds_finish does as a launch of its own) and leaves them in `minmax_out`.
+__global__ __launch_bounds__(64) void k_make_ladder(const double* __restrict__ minmax_in,
+                                                    const uint64_t* __restrict__ partial, int blocks,
+                                                    double* __restrict__ minmax_out, LadderSpec P,
+                                                    ScaleDev* __restrict__ ladder, OrderDev* __restrict__ order_dev,
+                                                    uint32_t* __restrict__ status)
 {
     const int sc = threadIdx.x;
+    double minmax[6];
+    if (partial) {
+        uint64_t v[6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            v[a] = ~0ull;
+            v[3 + a] = 0ull;
+        }
+        for (int b = sc; b < blocks; b += 64) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const uint64_t l = partial[b * 6 + a], h = partial[b * 6 + 3 + a];
+                v[a] = l < v[a] ? l : v[a];
+                v[3 + a] = h > v[3 + a] ? h : v[3 + a];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const uint64_t l = (uint64_t)__shfl_xor((unsigned long long)v[a], off);
+                const uint64_t h = (uint64_t)__shfl_xor((unsigned long long)v[3 + a], off);
+                v[a] = l < v[a] ? l : v[a];
+                v[3 + a] = h > v[3 + a] ? h : v[3 + a];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) minmax[a] = nm_order_decode(v[a]);
+        if (sc == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) minmax_out[a] = minmax[a];
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) minmax[a] = minmax_in[a];
+    }
     if (sc < P.n_scales) {
         ScaleDev S;
         const double e = P.edge[sc];
@@ -1337,7 +1256,8 @@ int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const dou
     return NM_OK;
 }
 
-int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const double* edges, const double* radii,
+int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const void* d_bounds_partial, int bounds_blocks,
+                   double* d_minmax_out, const double* edges, const double* radii,
                    int n_scales, int finest, void* const* hash, void* const* leaf, void* const* counters,
                    uint32_t hash_capacity, uint32_t leaf_capacity, ScaleDev* d_ladder, OrderDev* d_order,
                    hipStream_t s)
@@ -1354,7 +1274,8 @@ int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const double* edges, con
     }
     P.hash_capacity = hash_capacity;
     P.leaf_capacity = leaf_capacity;
-    k_make_ladder<<<1, 64, 0, s>>>(d_minmax, P, d_ladder, d_order, ctx->d_status);
+    k_make_ladder<<<1, 64, 0, s>>>(d_minmax, (const uint64_t*)d_bounds_partial, bounds_blocks, d_minmax_out, P,
+                                   d_ladder, d_order, ctx->d_status);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }

@@ -31,21 +31,21 @@ class Runtime(object):
         self._work = None
 
     def check(self, rc):
+        if rc == _ffi.NM_ERR_LATTICE:
+            # a lattice a kernel of an EARLIER call could not address, met at the entry of this one (NM_ENTER),
+            # or this call's own: either way a property of one call's arguments, not of the context - raise it
+            # once as the ValueError of VoxelFilter.__init__ (geometry.py:59-60) and leave the context usable
+            msg = self.lib.nm_last_error(self.ctx)
+            msg = msg.decode("utf-8", "replace") if msg else "lattice cannot be addressed"
+            self.lib.nm_clear_error(self.ctx)
+            raise ValueError(msg)
         _ffi.check(self.lib, self.ctx, rc)
 
     def check_async(self, wait=True):
         """raise what a kernel of an earlier call reported (nm_check): an occupancy index that timed out
         or overflowed, a lattice built on the device that cannot be addressed.  wait=True waits for the
         status snapshot of the last call - callers that have just synchronised pay nothing."""
-        rc = self.lib.nm_check(self.ctx, 1 if wait else 0)
-        if rc == _ffi.NM_ERR_LATTICE:
-            # what VoxelFilter.__init__ would have raised on the host (geometry.py:59-60): a property of
-            # that call's arguments, not of the context - report it once and carry on
-            msg = self.lib.nm_last_error(self.ctx)
-            msg = msg.decode("utf-8", "replace") if msg else "lattice cannot be addressed"
-            self.lib.nm_clear_error(self.ctx)
-            raise ValueError(msg)
-        self.check(rc)
+        self.check(self.lib.nm_check(self.ctx, 1 if wait else 0))
 
     def clear_error(self):
         self.check(self.lib.nm_clear_error(self.ctx))

@@ -86,18 +86,25 @@ class RcclComm(object):
             world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank, self.world = int(rank), int(world)
         uid = ctypes.create_string_buffer(_ffi.NM_COMM_ID_BYTES)
+        failed = 0
         if self.rank == 0:
-            rc = self.rt.lib.nm_comm_unique_id(uid)
-            if rc != _ffi.NM_OK:
-                raise _ffi.NimrudHipError("nm_comm_unique_id failed with status %d" % rc)
+            failed = self.rt.lib.nm_comm_unique_id(uid)
         if self.world > 1:
+            # rank 0 broadcasts in any case - the id, or the word that it has none - so that the other ranks
+            # never wait for a rank that has raised
+            message = bytes(uid.raw) if failed == _ffi.NM_OK else b"FAILED %d" % failed
             if broadcast is None:
-                box = [bytes(uid.raw)]
+                box = [message]
                 dist.broadcast_object_list(box, src=0)
                 payload = box[0]
             else:
-                payload = broadcast(bytes(uid.raw))
+                payload = broadcast(message)
+            if payload.startswith(b"FAILED"):
+                raise _ffi.NimrudHipError("rank 0: nm_comm_unique_id failed with status %s"
+                                          % payload[7:].decode("ascii", "replace"))
             uid = ctypes.create_string_buffer(payload, _ffi.NM_COMM_ID_BYTES)
+        elif failed != _ffi.NM_OK:
+            raise _ffi.NimrudHipError("nm_comm_unique_id failed with status %d" % failed)
         handle = ctypes.c_void_p()
         self.rt.check(self.rt.lib.nm_comm_create(self.rt.ctx, self.world, self.rank, uid,
                                                  ctypes.byref(handle)))
@@ -351,7 +358,8 @@ def process_tile(plan, out=None):
         out = torch.empty((n, 4 * n_scales), dtype=torch.float64, device=cloud.device)
     info = torch.zeros((max(n_scales, 1), 4), dtype=torch.int64, device=cloud.device) \
         if plan.want_info else None
-    be.features(search, n, bounds, plan.edge_lengths, plan.radii, out, info)
+    if n > 0:      # an empty tile took part in the exchange (the others may need nothing from it) and has no rows
+        be.features(search, n, bounds, plan.edge_lengths, plan.radii, out, info)
     plan._info = info
     return out
 

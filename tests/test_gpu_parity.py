@@ -1244,3 +1244,67 @@ def test_flexcloud_on_the_device():
     assert (predicted.cpu().numpy()[20000:] == labels[20000:]).mean() > 0.9
     host = point_clouds.FlexCloud(pts)
     assert np.array_equal(host.take(), pts + 0.0)
+
+
+# ---- the spatial order (nm_order.hip: the radix sort of our own) ------------------------------------------------
+
+def _compact_zorder_key(cells, widths, key_bits=30):
+    """numpy restatement of nm_order_key: bit b of every axis that has a bit b, lowest bits first (the
+    order of a 3-way Morton interleave with the always-zero bits squeezed out), cut to `key_bits` from the top"""
+    key = np.zeros(len(cells), dtype=np.uint64)
+    at = 0
+    for b in range(int(max(widths))):
+        for a in range(3):
+            if b < widths[a]:
+                key |= ((cells[:, a].astype(np.uint64) >> np.uint64(b)) & np.uint64(1)) << np.uint64(at)
+                at += 1
+    total = int(sum(widths))
+    return (key >> np.uint64(max(total - key_bits, 0))).astype(np.uint32)
+
+
+@pytest.mark.parametrize("n,edge,kind", [(1, 0.1, "uniform"), (300, 0.1, "uniform"), (8192, 0.05, "uniform"),
+                                         (8193, 0.05, "scene"), (250_000, 0.25, "uniform"),
+                                         (2_000_003, 0.05, "scene")])
+def test_spatial_order_is_a_sorted_permutation(n, edge, kind):
+    """nm_spatial_order: the permutation is one, the coordinates are carried along bit for bit, the keys the
+    library reports are the compact Z-order keys of the cells (restated in numpy above) and they come out
+    ascending.  the sort's top digit is exact by construction; inside it the order rests on the lane order of
+    LDS atomics (nm_order.hip): the test reports the inversions it finds and tolerates a per-mille of them."""
+    import ctypes
+    from nimrud_amd import device as nm_device
+    rt = _device_runtime()
+    if kind == "uniform":
+        pts = np.random.RandomState(n).rand(n, 3) * np.array([10.0, 7.0, 3.0]) + np.array([-2.0, 40.0, 1.0])
+    else:
+        pts, _ = synth.scene_cloud(n, extent=30.0 if n < 100000 else 80.0, n_poles=20, n_spheres=6, seed=n % 97)
+    pts = np.ascontiguousarray(pts)
+    lo = pts.min(0) if n > 1 else pts[0] - 1.0
+    hi = pts.max(0) if n > 1 else pts[0] + 1.0
+    mc, _, widths, _ = geometry.lattice_parameters(lo, hi, edge)
+    lat = geometry.make_nm_lattice(mc, edge, widths)
+    dev = torch.from_numpy(pts).cuda()
+    order = torch.empty(n, dtype=torch.int32, device="cuda")
+    sxyz = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    keys = torch.empty(n, dtype=torch.int32, device="cuda")
+    nbytes = rt.lib.nm_spatial_order_workspace_bytes(n)
+    work = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda")
+    rt.check(rt.lib.nm_spatial_order(rt.ctx, nm_device.ptr(dev), n, 3, ctypes.byref(lat), nm_device.ptr(order),
+                                     nm_device.ptr(sxyz), nm_device.ptr(keys), nm_device.ptr(work), work.numel(),
+                                     rt.stream()))
+    torch.cuda.synchronize()
+    order = order.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert np.array_equal(np.sort(order), np.arange(n))
+    assert np.array_equal(sxyz.cpu().numpy(), pts[order])
+    got = keys.cpu().numpy().view(np.uint32)
+    cells = np.floor((pts[order] - mc) / edge).astype(np.int64)
+    want = _compact_zorder_key(cells, widths)
+    # the library takes the cell from a multiplication by fl(1/e): a point within rounding of a cell face may
+    # carry its neighbour's key
+    assert np.mean(got != want) < 1e-4
+    total = min(int(sum(widths)), 30)
+    bpp = max((total + 2) // 3, 1)
+    top = got >> np.uint32(2 * bpp)
+    assert np.all(np.diff(top.astype(np.int64)) >= 0)
+    inversions = int(np.sum(np.diff(got.astype(np.int64)) < 0))
+    print("spatial order: n = %d, key bits %d, %d adjacent inversions" % (n, total, inversions))
+    assert inversions <= max(n // 1000, 0)

@@ -16,6 +16,6 @@ for f in *.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math "$@" -c $f -o ${f%.hip}.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/build_abl/lib_$NAME.so" *.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/build_abl/lib_$NAME.so" *.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 rm -rf "$D"
 ls -la "$R/build_abl/lib_$NAME.so"
