@@ -240,16 +240,28 @@ def classify_cloud(cloud, edge_lengths, radii, model, fused=True, want_proba=Fal
     (nm_set_forest_output): the wave that has just finished a row reads it back out of L2 and its 64
     spatially neighbouring lanes walk the trees together.  forests outside the fused path's limits (more
     than 20 features or 8 classes) and fused=False evaluate the finished matrix with nm_forest_eval; the
-    numbers are the same."""
+    numbers are the same.  other keyword arguments go to process_gpu (strict, knn_min, ...); with
+    return_info=True the per-scale ScaleInfo list is appended to the returned tuple."""
     from nimrud_amd.minimal import multiscale
     n_features = 4 * len(edge_lengths)
+    # return_info=True (process_gpu's per-scale ScaleInfo list) is passed on and comes back as the last element
+    want_info = bool(kwargs.pop("return_info", False))
     can_fuse = (fused and model.packed8 is not None and model.n_features == n_features and
                 n_features <= FUSED_MAX_FEATURES and model._c.n_classes <= FUSED_MAX_CLASSES and
                 not kwargs.get("verbose") and not kwargs.get("per_scale"))
+
+    def features_of(q):
+        res = multiscale.process_gpu(q, q, edge_lengths, radii, out=out, return_info=want_info, **kwargs)
+        return res if want_info else (res, None)
+
+    def result(label, proba, feats, info):
+        parts = (label, proba, feats) if want_proba else (label, feats)
+        return parts + (info,) if want_info else parts
+
     if not can_fuse:
-        feats = multiscale.process_gpu(cloud, cloud, edge_lengths, radii, out=out, **kwargs)
+        feats, info = features_of(cloud)
         proba, label, _ = model._eval(feats, want_proba, True)
-        return (label, proba, feats) if want_proba else (label, feats)
+        return result(label, proba, feats, info)
     rt, dev_cloud = _device.as_cloud(cloud)
     n = dev_cloud.shape[0]
     label = torch.empty(n, dtype=torch.int32, device=rt.device)
@@ -258,7 +270,7 @@ def classify_cloud(cloud, edge_lengths, radii, model, fused=True, want_proba=Fal
     rt.check(rt.lib.nm_set_forest_output(rt.ctx, ctypes.byref(model._c), _device.ptr(proba),
                                          model._c.n_classes, _device.ptr(label)))
     try:
-        feats = multiscale.process_gpu(dev_cloud, dev_cloud, edge_lengths, radii, out=out, **kwargs)
+        feats, info = features_of(dev_cloud)
     finally:
         rt.check(rt.lib.nm_set_forest_output(rt.ctx, None, None, 0, None))
-    return (label, proba, feats) if want_proba else (label, feats)
+    return result(label, proba, feats, info)

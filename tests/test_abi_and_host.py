@@ -198,3 +198,61 @@ def test_forest_node_packing_is_exact_on_the_config5_fixture():
     assert np.abs(proba - g["proba"]).max() <= 1e-15
     assert np.array_equal(proba.argmax(1), g["label"])
     assert ForestModel.pack_nodes8(rec, 33) is None             # more features than the 5-bit field holds
+
+
+def test_halo_plan_from_count_matrix():
+    """nm_halo_plan_from_matrix: the host half of nm_halo_exchange's step 3 (offsets, totals, the verdict every
+    rank must share), on synthetic count matrices for 2 and 3 ranks - ordering of the receive offsets against
+    the senders' segments, one rank short of room, one rank unwell.  no GPU, no communicator."""
+    import ctypes
+    import numpy as np
+    from nimrud_amd import _ffi
+    lib = _ffi.load()
+
+    def plan(matrix, rank):
+        m = np.ascontiguousarray(matrix, dtype=np.int64)
+        world = m.shape[0]
+        send_off = (ctypes.c_int64 * world)()
+        recv_off = (ctypes.c_int64 * world)()
+        sent, recv, culprit = ctypes.c_int64(-1), ctypes.c_int64(-1), ctypes.c_int32(-7)
+        rc = lib.nm_halo_plan_from_matrix(m.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), world, rank,
+                                          send_off, recv_off, ctypes.byref(sent), ctypes.byref(recv),
+                                          ctypes.byref(culprit))
+        return rc, list(send_off), list(recv_off), sent.value, recv.value, culprit.value
+
+    rs = np.random.RandomState(5)
+    for world in (2, 3):
+        pairs = rs.randint(0, 50, size=(world, world))
+        np.fill_diagonal(pairs, 0)
+        cap = np.full((world, 2), 1000)
+        matrix = np.hstack([pairs, cap, np.zeros((world, 1), dtype=np.int64)])
+        for rank in range(world):
+            rc, send_off, recv_off, sent, recv, culprit = plan(matrix, rank)
+            assert rc == _ffi.NM_OK and culprit == -1
+            assert send_off == list(np.concatenate([[0], np.cumsum(pairs[rank])[:-1]]))
+            assert recv_off == list(np.concatenate([[0], np.cumsum(pairs[:, rank])[:-1]]))     # in rank order
+            assert sent == pairs[rank].sum() and recv == pairs[:, rank].sum()
+        # exactly one rank is short of room (receive side): EVERY rank gets the same verdict and culprit,
+        # and still learns its own totals (that is what it grows its buffers by)
+        short = world - 1
+        tight = matrix.copy()
+        tight[short, world + 1] = pairs[:, short].sum() - 1
+        verdicts = [plan(tight, rank) for rank in range(world)]
+        assert all(v[0] == _ffi.NM_ERR_WORKSPACE and v[5] == short for v in verdicts)
+        assert [v[3] for v in verdicts] == list(pairs.sum(1)) and [v[4] for v in verdicts] == list(pairs.sum(0))
+        # send side
+        tight = matrix.copy()
+        tight[0, world] = pairs[0].sum() - 1
+        assert all(plan(tight, rank)[0] == _ffi.NM_ERR_WORKSPACE and plan(tight, rank)[5] == 0
+                   for rank in range(world))
+        # one rank unwell (a sticky failure of an earlier call): every rank returns ITS status, before any
+        # capacity question
+        sick = matrix.copy()
+        sick[1, world + 2] = _ffi.NM_ERR_HIP
+        sick[0, world] = 0
+        assert all(plan(sick, rank)[0] == _ffi.NM_ERR_HIP and plan(sick, rank)[5] == 1 for rank in range(world))
+    # an empty tile: zero row and zero column
+    matrix = np.array([[0, 0, 0, 10, 10, 0], [0, 0, 5, 10, 10, 0], [0, 3, 0, 10, 10, 0]])
+    rc, send_off, recv_off, sent, recv, _ = plan(matrix, 0)
+    assert rc == _ffi.NM_OK and sent == 0 and recv == 0
+    assert lib.nm_halo_plan_from_matrix(None, 2, 0, None, None, None, None, None) == _ffi.NM_ERR_INVALID

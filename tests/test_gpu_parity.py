@@ -417,6 +417,46 @@ def test_halo_exchange_through_rccl_one_rank(halo):
         comm.close()
 
 
+def test_halo_exchange_with_an_empty_tile_and_with_an_unwell_rank():
+    """nm_halo_exchange must never leave a rank alone in a collective: an EMPTY tile takes part (empty box,
+    empty cell set, nothing sent or received), and a rank that alone is unwell (here: a sticky lattice report
+    of an earlier call) goes through the all-gathers and every rank returns its status afterwards.  one-rank
+    RCCL communicator: the collectives and the status word run on hardware."""
+    import ctypes
+    from nimrud_amd import _ffi, parallel, device as nm_device
+    rt = _device_runtime()
+    comm = parallel.RcclComm(rank=0, world=1)
+    try:
+        empty = torch.empty((0, 3), dtype=torch.float64, device="cuda")
+        plan = parallel.TilePlan(empty, [0.1, 0.2], [0.3, 0.6], comm=comm, halo="cells")
+        plan.include_self = True
+        out = parallel.process_tile(plan)
+        torch.cuda.synchronize()
+        assert out.shape == (0, 8) and plan.halo_received == 0 and plan.halo_sent == 0
+        # an unwell rank: leave a lattice report in the context, then enter the exchange without looking
+        pts = synth.uniform_cloud(4000, extent=2.0, seed=77)
+        dev = torch.from_numpy(pts).cuda()
+        multiscale.process_gpu(dev, dev, [1e-9], [3e-9])
+        torch.cuda.synchronize()
+        work = torch.empty(int(rt.lib.nm_halo_workspace_bytes(8000, 1)), dtype=torch.uint8, device="cuda")
+        recv = torch.empty((8000, 3), dtype=torch.float64, device="cuda")
+        glob = torch.empty(6, dtype=torch.float64, device="cuda")
+        sent, received = ctypes.c_int64(0), ctypes.c_int64(0)
+        rc = rt.lib.nm_halo_exchange(rt.ctx, comm.handle, 1, 0, nm_device.ptr(dev), 4000, 3, 0.5,
+                                     parallel.HALO_CELLS | parallel.HALO_INCLUDE_SELF, nm_device.ptr(recv), 8000,
+                                     ctypes.byref(received), ctypes.byref(sent), nm_device.ptr(glob),
+                                     nm_device.ptr(work), work.numel(), rt.stream())
+        assert rc == _ffi.NM_ERR_LATTICE         # after the collectives, not before them
+        with pytest.raises(ValueError, match="too small"):
+            rt.check(rc)
+        # reported once; the context and the communicator carry on
+        plan = parallel.TilePlan(dev, [0.1], [0.3], comm=comm, halo="cells")
+        out = parallel.process_tile(plan)
+        assert torch.equal(out, multiscale.process_gpu(dev, dev, [0.1], [0.3]))
+    finally:
+        comm.close()
+
+
 def test_prefix_query_mode_matches_separate_clouds():
     # queries = leading rows of the search buffer (what a tile + halo looks like)
     pts, _ = synth.scene_cloud(40000, extent=12.0, n_poles=8, n_spheres=3, seed=93)
@@ -1211,6 +1251,34 @@ def test_classify_cloud_end_to_end():
     conf = classification.confusion_matrix(pred[torch.from_numpy(va).cuda()],
                                            torch.from_numpy(labels[va]).cuda(), n_classes=3)
     assert conf.sum() == len(va) and np.trace(conf) / conf.sum() > 0.9
+    # keyword arguments of process_gpu pass through; return_info comes back as the last element, on both paths
+    for fused in (True, False):
+        pred3, feats3, info = classification.classify_cloud(dev, edges, radii, model, fused=fused,
+                                                            return_info=True)
+        assert torch.equal(pred3, pred) and torch.equal(feats3, feats) and len(info) == 3
+        assert [i.voxels for i in info] == [len(oracle.Lattice(pts, e).unique_addresses(pts)) for e in edges]
+
+
+def test_unusable_lattice_never_looks_like_features_and_never_poisons_the_context():
+    """process_gpu only enqueues: a lattice the device cannot address is reported at the next synchronisation
+    point.  until then the columns of that scale hold NaN (labels -1 behind a fused
+    forest), never uninitialised memory; and whichever call meets the report first - nm_check or the entry of
+    the next library call - raises the reference's ValueError (geometry.py:59-60) ONCE and leaves the context
+    usable."""
+    pts = synth.uniform_cloud(5000, extent=2.0, seed=4242)
+    dev = torch.from_numpy(pts).cuda()
+    out = torch.full((5000, 8), 7.0, dtype=torch.float64, device="cuda")
+    multiscale.process_gpu(dev, dev, [0.1, 1e-9], [0.3, 3e-9], out=out)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    assert np.isnan(host[:, 4:]).all()
+    assert_features_close(host[:, :4], oracle.process_fast(pts, pts, [0.1], [0.3]), pts)
+    # no check_async: the next call into the library meets the report at its entry
+    with pytest.raises(ValueError, match="too small"):
+        multiscale.process_gpu(dev, dev, [0.1], [0.3])
+    got = multiscale.process_gpu(dev, dev, [0.1], [0.3]).cpu().numpy()       # once: the context carries on
+    assert_features_close(got, host[:, :4], pts)
+    _device_runtime().check_async(wait=True)
 
 
 def test_verbose_mode_prints_like_the_reference(capsys):
