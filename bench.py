@@ -32,11 +32,11 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
 
 
 def _profile_json(name):
-    for rnd in (PROFILE_ROUND, "r1_final"):
+    for rnd in (PROFILE_ROUND, "r2", "r1_final"):
         path = os.path.join(REPO, "profiles", "%s_%s.json" % (rnd, name))
         if os.path.exists(path):
             try:
@@ -60,31 +60,68 @@ def measured_traffic(points_per_gpu, kernel_prefix):
     return None, None
 
 
+def _issue_costs():
+    """SIMD cycles per wave64 instruction by class, measured on this part by tools/issue_rate.hip (profiles/
+    r3_issue_rate.json; the column for 4 waves per SIMD - the search kernel runs 5, one-wave workgroups like the
+    probe's).  None when the table is not there."""
+    data, path = _profile_json("issue_rate")
+    if data is None:
+        return None, None
+    try:
+        col = data["waves_per_simd"].index(4)
+        c = {k: float(v[col]) for k, v in data["cycles"].items()}
+        return c, path
+    except Exception:   # noqa: BLE001
+        return None, None
+
+
 def valu_ceiling(n_queries, kernel_ms):
     """the second roofline SURVEY 8d asks for: the ALU candidate-test ceiling.  from the committed SQ
-    counters of the dominant kernel (instructions per wave by class, mean over the five scales of the
-    step; tools/collect_profiles.sh) and the live query rate: fp64 flop per query x queries/s against
-    the fp64 vector peak, next to how full the vector-ALU issue slots are."""
+    counters of the dominant kernel (instructions per wave by class, mean over the scales of the launch;
+    tools/collect_profiles_r3.sh), the live query rate and the MEASURED issue cost of each class
+    (tools/issue_rate.hip): fp64 flop per query x queries/s against the fp64 vector peak, next to how much of
+    the SIMDs' time the instruction stream accounts for.  the counters do not split the 32-bit integer and
+    the uncategorised instructions into the part's two cost classes (v_add_u32 / v_and / v_bitop3 / v_mov:
+    one half the cost of v_alignbit / shifts / v_mad_u32_u24 / v_cmp / DPP, which cost what an fp64 add
+    does), so the busy fraction is given as a bracket, with the static opcode mix of the kernel's main path in
+    between (profiles/r3_issue_model.json, tools/issue_model.py)."""
     data, path = _profile_json("instruction_mix")
     if data is None or "per_wave" not in data:
         return None
     try:
         pw = {k: float(np.mean(v)) for k, v in data["per_wave"].items()}
-        flop = (pw["SQ_INSTS_VALU_ADD_F64"] + pw["SQ_INSTS_VALU_MUL_F64"] +
-                2.0 * pw["SQ_INSTS_VALU_FMA_F64"] + pw["SQ_INSTS_VALU_TRANS_F64"])
+        f64 = pw["SQ_INSTS_VALU_ADD_F64"] + pw["SQ_INSTS_VALU_MUL_F64"] + pw["SQ_INSTS_VALU_FMA_F64"]
+        flop = f64 + pw["SQ_INSTS_VALU_FMA_F64"] + pw["SQ_INSTS_VALU_TRANS_F64"]
         queries_per_s = n_queries / (kernel_ms * 1e-3)
         tflops = flop * queries_per_s / 1e12       # one lane of a wave instruction = one query's flop
-        # issue slots: SQ_ACTIVE_INST_VALU counts quad-cycles per wave; 1024 SIMDs at the 2.4 GHz
-        # maximum clock (the clock held under load is lower, so this fraction is a lower bound)
-        simd_cycles = kernel_ms * 1e-3 * 2.4e9 * 1024
-        busy = (n_queries / 64.0) * pw["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
-        return {"bound": "valu-issue", "valu_instr_per_wave": pw["SQ_INSTS_VALU"],
-                "fp64_instr_per_wave": flop - pw["SQ_INSTS_VALU_FMA_F64"],
-                "fp64_flop_per_query": flop,
-                "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
-                "valu_issue_busy_frac": busy,
-                "source": path}
+        rec = {"bound": "valu-issue", "valu_instr_per_wave": pw["SQ_INSTS_VALU"],
+               "fp64_instr_per_wave": f64 + pw["SQ_INSTS_VALU_TRANS_F64"],
+               "fp64_flop_per_query": flop,
+               "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "source": path}
+        cost, cost_path = _issue_costs()
+        if cost is not None:
+            # SIMD cycles one wave-scale has at the maximum clock (the costs are quoted at that clock too)
+            simd_cycles_per_wave = kernel_ms * 1e-3 * 2.4e9 * 1024 / (n_queries / 64.0)
+            fixed = (f64 * cost["v_add_f64"] + pw["SQ_INSTS_VALU_TRANS_F64"] * cost["v_rcp_f64"] +
+                     pw["SQ_INSTS_VALU_INT64"] * cost["v_lshrrev_b64"] +
+                     pw["SQ_INSTS_VALU_CVT"] * cost["v_cvt_f64_u32"])
+            loose = pw["SQ_INSTS_VALU"] - f64 - pw["SQ_INSTS_VALU_TRANS_F64"] - pw["SQ_INSTS_VALU_INT64"] - \
+                pw["SQ_INSTS_VALU_CVT"]
+            lo = (fixed + loose * cost["v_add_u32"]) / simd_cycles_per_wave
+            hi = (fixed + loose * cost["v_alignbit_b32 (imm)"]) / simd_cycles_per_wave
+            rec.update({"issue_cost_source": cost_path,
+                        "issue_cycles_per_class": {"fp64 add/mul/fma": cost["v_add_f64"],
+                                                   "fp64 rcp/rsq": cost["v_rcp_f64"],
+                                                   "alignbit/shift/mad24/cmp/dpp": cost["v_alignbit_b32 (imm)"],
+                                                   "add/and/bitop3/mov": cost["v_add_u32"]},
+                        "simd_cycles_per_wave_and_scale": simd_cycles_per_wave,
+                        "valu_issue_busy_frac_bracket": [lo, hi]})
+            model, model_path = _profile_json("issue_model")
+            if model is not None and "main_path_issue_cycles" in model:
+                rec["valu_issue_busy_frac"] = float(model["main_path_issue_cycles"]) / simd_cycles_per_wave
+                rec["issue_model_source"] = model_path
+        return rec
     except Exception:   # noqa: BLE001
         return None
 
@@ -105,6 +142,10 @@ def parse_args():
                     help="nm_set_fuse_scales value (1 = one search launch walks all scales, 0 = one per scale)")
     ap.add_argument("--cpu-sample", type=int, default=150000,
                     help="points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--emit-indices", action="store_true",
+                    help="index-emission (parity) mode: a step writes the neighbor index lists of the workload's "
+                         "FINEST scale (multiscale.py:103) as CSR instead of features; value = point-scales/s "
+                         "of that, roofline adds 8 * mean list length bytes per point-scale (SURVEY 8d)")
     return ap.parse_args()
 
 
@@ -190,6 +231,56 @@ def cpu_forest(model_arrays, feature_rows):
                                       % (len(feature_rows), dt)}
 
 
+def bench_emit_indices(args, cfg, cloud, edges, radii, dev, n_cloud):
+    """index-emission (parity) mode, SURVEY 8(d): a step = the neighbor index lists of the finest scale for
+    every query - voxelize the search cloud (sorted unique addresses: np.unique, geometry.py:150), count,
+    prefix, emit (multiscale.py:103) - through multiscale.neighbor_lists, everything resident in HBM.  the
+    two launches of k_scale_neighbors (count, then emit) are timed with events on the stream they run on."""
+    import torch
+    from nimrud_amd.minimal import multiscale
+    finest = int(np.argmin(edges))
+    e, r = edges[finest], radii[finest]
+    nq = cloud.shape[0]
+
+    def step():
+        return multiscale.neighbor_lists(cloud, cloud, e, r)
+
+    for _ in range(max(args.warmup, 1)):
+        off, idx = step()
+    torch.cuda.synchronize(dev)
+    total = int(idx.shape[0])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    m = int(multiscale.geometry.VoxelFilter(cloud[:, :3], e, device=dev).unique_addresses(cloud[:, :3]).shape[0])
+    k_mean = total / float(nq)
+    # algorithmic bytes of one step (SURVEY 8d plus its index term): read the search cloud for the voxelize
+    # (24 N), write and read the unique addresses (16 M), read the queries (24 N), write offsets (8 N) and the
+    # index lists (8 k N)
+    alg_bytes = 24.0 * nq + 16.0 * m + 24.0 * nq + 8.0 * nq + 8.0 * total
+    ms = elapsed / args.steps * 1e3
+    record = {
+        "metric": "point-scale neighbor-list ops/sec (index emission, parity mode)",
+        "value": nq * args.steps / elapsed, "unit": "point-scales/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s: %d points, index lists of the finest scale e=%g r=%g for every query "
+                               "(CSR, int64 ranks in the sorted unique voxel addresses)"
+                               % (args.workload, n_cloud, e, r),
+                   "points_per_gpu": nq, "scales": 1, "parallelism": "tiles1"},
+        "roofline": {"bound": "hbm", "kernel": "nm_voxelize + k_scale_neighbors (count) + k_scale_neighbors (emit)",
+                     "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "alg_bytes_per_step": alg_bytes, "index_bytes_per_point_scale": 8.0 * k_mean,
+                     "note": "whole step, not one launch: the emission is a chain of dependent binary searches "
+                             "in the address array, latency-bound, nowhere near either roofline"},
+        "voxels": m, "mean_neighbors_per_query": k_mean, "cpu_baseline": None,
+    }
+    print(json.dumps(record))
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -232,11 +323,17 @@ def main():
         forest_arrays["n_features"] = int(fixture["n_features"])
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         cpu["cpu_baseline"] = cpu_baseline(points, edges, radii, args.cpu_sample)
-        workers = min(32, os.cpu_count() or 1)
+        # "all host cores", a 1 M-point slice for configs 2-5.  the box gives one GPU's job a share
+        # of 16 cpus (more worker processes than that only fight for them, and the box kills a run above its
+        # process limit): 16 workers, or fewer when the host has fewer; NIMRUD_BENCH_CPU_WORKERS overrides.
+        # the slice is 1 M points (the whole cloud when it is smaller) unless --cpu-sample asks for less
+        workers = int(os.environ.get("NIMRUD_BENCH_CPU_WORKERS", "0")) or min(16, os.cpu_count() or 1)
+        multi_sample = min(len(points), 1_000_000) if args.cpu_sample >= 150000 else args.cpu_sample
         if workers > 1:
             try:
                 cpu["cpu_baseline_multicore"] = cpu_baseline_multicore(points, edges, radii,
-                                                                       args.cpu_sample, workers)
+                                                                       multi_sample, workers)
+                cpu["cpu_baseline_multicore"]["host_cpus"] = os.cpu_count()
             except Exception as err:   # noqa: BLE001 - a reported extra, never fatal
                 cpu["cpu_baseline_multicore"] = {"error": str(err)[:200]}
         try:
@@ -299,6 +396,11 @@ def main():
 
         def features_step():
             return multiscale.process_gpu(cloud, cloud, edges, radii, out=out)
+
+    if args.emit_indices:
+        if world != 1 or classify:
+            raise SystemExit("--emit-indices is a single-GPU feature-free mode")
+        return bench_emit_indices(args, cfg, cloud, edges, radii, dev, n_cloud)
 
     fused = os.environ.get("NIMRUD_BENCH_FUSED_FOREST", "1") != "0"
     if os.environ.get("NIMRUD_BENCH_FOREST_EPILOGUE"):
@@ -450,10 +552,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d-point plane+pole+sphere scene%s, %d scales e=%s r=3e, "
-                            "query cloud = search cloud, rows in Morton order of the coarsest cell"
-                            % (args.workload, n_cloud, "" if (strong or world == 1) else " per GPU",
-                               n_scales, edges),
+                "workload": "%s: %d-point %s%s, %d scales e=%s r=%s, query cloud = search cloud%s"
+                            % (args.workload, n_cloud,
+                               {"uniform": "uniform-random cloud in a cube", "scene": "plane+pole+sphere scene",
+                                "lidar": "terrestrial-LiDAR-style cloud (power-law density)"}[cfg["kind"]],
+                               "" if (strong or world == 1) else " per GPU", n_scales, edges, radii,
+                               ", rows in Morton order of the %g m cell" % cfg["morton"] if cfg.get("morton")
+                               else ", rows in generation order"),
                 "points_per_gpu": nq,
                 "scales": n_scales,
                 "parallelism": "tiles%d" % world,

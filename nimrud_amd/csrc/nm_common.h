@@ -244,6 +244,11 @@ struct ScaleDev {
     double r2;               // radius * radius (fp64 product, as scipy forms it)
     int32_t valid;           // 0: the lattice cannot be addressed; every kernel leaves at once
     int32_t prune_ok;        // static pruning of the candidate window is sound for this lattice
+    uint32_t* stats;         // this scale's own counter block: [8] neighborhoods below 2 voxels, [9] extra passes
+    int32_t shared;          // 1: same edge length as an earlier scale of the ladder - same lattice, and I is THAT
+                             // scale's index (the reference's ladders look like this: one voxel edge, several
+                             // radii - nimrud/utils/point_clouds.py:29-35); nobody clears, builds or counts it twice
+    int32_t reserved;
 };
 
 // how the three axes share the compact Z-order key of the one-time spatial sort (k_order_keys)

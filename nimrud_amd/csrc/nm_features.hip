@@ -29,6 +29,9 @@ constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anch
 #ifndef NM_CENTRE_TABLE
 #define NM_CENTRE_TABLE 1
 #endif
+#ifndef NM_SLAB_MIN_W
+#define NM_SLAB_MIN_W 11        // windows this wide and wider take the slab-fused path of the search kernel
+#endif
 constexpr int NM_BOX_EX = 62;   // x extent of a staged box: 64-bit rows, kept shifted left by two
 
 // one launch of the search kernel: the scales [s_begin, s_end) of a ladder whose per-scale data (lattice,
@@ -511,7 +514,7 @@ constexpr RowBound nm_row_bound(int W, double rho2, int j, int k)
     return RowBound{(int8_t)a, (int8_t)b};
 }
 
-constexpr int NM_MAX_W = 9;
+constexpr int NM_MAX_W = 11;
 struct RowBoundTable {
     RowBound rb[NM_MAX_W * NM_MAX_W];   // [j * W + k]
 };
@@ -530,6 +533,19 @@ constexpr RowBoundTable nm_make_bounds(double rho2, bool prune)
 // the benchmark ratio r = 3e gets its table at compile time, so the unrolled loops contain only the
 // tests that can matter
 constexpr RowBoundTable NM_BOUNDS_RHO3 = nm_make_bounds<7>(9.0, true);
+// r = 4e and r = 5e (the reference's example ladder is one voxel edge with radii of 3, 4 and 5 edges:
+// nimrud/utils/point_clouds.py:29-35) get theirs at compile time too: with the table in a kernel parameter it
+// lives in 40-60 scalar registers and the kernel spills a thousand of them
+constexpr RowBoundTable NM_BOUNDS_RHO4 = nm_make_bounds<9>(16.0, true);
+constexpr RowBoundTable NM_BOUNDS_RHO5 = nm_make_bounds<11>(25.0, true);
+// the compile-time table of an integer ratio RHO (W = 2 RHO + 1)
+template <int RHO>
+constexpr const RowBoundTable& nm_static_bounds()
+{
+    if constexpr (RHO == 3) return NM_BOUNDS_RHO3;
+    else if constexpr (RHO == 4) return NM_BOUNDS_RHO4;
+    else return NM_BOUNDS_RHO5;
+}
 
 // ---- the inside/outside masks of a query's window, as the search kernel packs them -------------------------
 // row (j, k) of the window has W bits, candidate c in bit 2 + (k % RPR) * W + c of register j * RPJ + k / RPR
@@ -626,8 +642,8 @@ __device__ const MomentLut<W> NM_LUT = nm_make_lut<W>();
 // used by the generic kernel (unusual radius/edge ratios) and, inside the table kernels, for lattices whose
 // coordinates are so large that the static pruning of the window is not sound.  same arithmetic.
 __device__ __forceinline__ void nm_lane_generic(const ScaleArgs& A, const LatticeDev& L, const IndexDev& I,
-                                                double r2, int32_t s, uint32_t qi, double qx, double qy,
-                                                double qz, bool* sparse_out)
+                                                uint32_t* stats, double r2, int32_t s, uint32_t qi, double qx,
+                                                double qy, double qz, bool* sparse_out)
 {
     const int32_t hx = nm_clamp_cell(nm_cell_f(qx, L.min_x, L.edge));
     const int32_t hy = nm_clamp_cell(nm_cell_f(qy, L.min_y, L.edge));
@@ -693,7 +709,7 @@ __device__ __forceinline__ void nm_lane_generic(const ScaleArgs& A, const Lattic
     if (A.normal)
         nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0,
                                A.normal + (int64_t)qi * A.nstride + 3 * s);
-    if (n < 2.0) atomicAdd(&I.counters[8], 1u);
+    if (n < 2.0) atomicAdd(&stats[8], 1u);
     *sparse_out = n < (double)A.sparse_k;
 }
 
@@ -886,13 +902,17 @@ __device__ __forceinline__ T* nm_row_ptr(T* base, uint32_t row, int64_t stride, 
     return base + ((uint64_t)row * (uint64_t)(uint32_t)stride + (uint64_t)(uint32_t)col);
 }
 
-template <int W, bool RHO3, bool FOREST, bool LOOP>
+// RHO: 0 = the window's static bounds come in the kernel parameter RT; 3, 4, 5 = r is that many edges and the
+// bounds are compile-time constants (RHO = 3, the benchmark's ratio, also has its tests chained at compile time)
+template <int W, int RHO, bool FOREST, bool LOOP>
 __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs A, RowBoundTable RT,
                                                        const ScaleDev* __restrict__ scales,
                                                        const uint2* __restrict__ forest_nodes)
 {
-    static_assert(W >= 3 && W <= 9 && (W & 1), "LUT kernel covers W = 3,5,7,9");
-    static_assert(!RHO3 || W == 7, "the compile-time table is for W = 7");
+    static_assert(W >= 3 && W <= 11 && (W & 1), "LUT kernel covers W = 3,5,7,9,11");
+    static_assert(RHO == 0 || W == 2 * RHO + 1, "a compile-time table is for the window of its ratio");
+    static_assert(RHO == 0 || (RHO >= 3 && RHO <= 5), "compile-time tables exist for r = 3e, 4e, 5e");
+    constexpr bool RHO3 = RHO == 3;
     constexpr int C = (W - 1) / 2;
     constexpr int RPR = 30 / W;                   // rows of the window per mask register, from bit 2
     constexpr int RPJ = (W + RPR - 1) / RPR;      // mask registers per y-slab
@@ -900,7 +920,11 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     static_assert(!RHO3 || (RPR == NM_RHO3_RPR && RPJ == NM_RHO3_RPJ), "layout of the compile-time chains");
     // one block of LDS: the staged rows, the superblock table and the moment table; the classifier's
     // feature stage reuses all of it after the last scale
-    constexpr int SEARCH_BYTES = ROWS_CAP * 8 + SBT_CAP * 4 + (4 << W);
+    // wide windows (W >= 11: 121 row masks would need 66 registers) test and walk one y-slab at a time INSIDE the
+    // pass loop, behind the staging: their centre table cannot share the row buffer
+    constexpr bool SLAB = W >= NM_SLAB_MIN_W;
+    constexpr int CTAB_OFS = ROWS_CAP * 8 + SBT_CAP * 4 + (4 << W);
+    constexpr int SEARCH_BYTES = CTAB_OFS + (SLAB ? 3 * 64 * 8 : 0);
     constexpr int STAGE_BYTES = FOREST ? NM_FUSED_FOREST_FEATURES * 64 * 4 : 0;   // = SEARCH_BYTES at W = 7
     constexpr int LDS_BYTES = SEARCH_BYTES > STAGE_BYTES ? SEARCH_BYTES : STAGE_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
@@ -985,7 +1009,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     wave_bbox(blox, bhix, bloy, bhiy, bloz, bhiz);
     const bool tab = NM_CENTRE_TABLE && blox <= bhix && (int64_t)bhix - blox + W <= 64 &&
                      (int64_t)bhiy - bloy + W <= 64 && (int64_t)bhiz - bloz + W <= 64;
-    double* ctab = (double*)rows;      // 3 x 64 doubles; the row buffer is not in use yet
+    double* ctab = SLAB ? (double*)(lds_raw + CTAB_OFS)
+                        : (double*)rows;      // 3 x 64 doubles; the row buffer is not in use yet
     lds_fence();                       // the previous scale's last pass has read the row buffer
     if (tab) {
         ctab[lane] = nm_centre(blox + dmin + lane, L.min_x, L.edge, L.half_edge);
@@ -1005,8 +1030,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
 
     // ---- phase A (once per wave and scale): the inside/outside bit of every candidate that needs a test,
     //      as W-bit row masks packed RPR to a register.  independent of the occupancy.
-    uint32_t inside[MASK_REGS];
-    {
+    uint32_t inside[SLAB ? 1 : MASK_REGS];
+    if constexpr (!SLAB) {
         // squared coordinate differences to the W candidate centres per axis (bit-identical centres)
         // index i of the y and z tables is in the lane's mirrored frame: cell = home + sgn*(i - C)
         double dx2[W], dy2[W], dz2[W];
@@ -1062,7 +1087,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             } else {
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    const RowBound rb = RT.rb[j * W + k];
+                    RowBound rb = RT.rb[j * W + k];
+                    if constexpr (RHO > 0) rb = nm_static_bounds<RHO>().rb[j * W + k];
                     // "outside" bits of the candidates C-b .. C+b (the ones further out are never inside: their
                     // bits of the row mask simply stay clear), candidate C-b in bit 0
                     if (rb.b < 0) continue;
@@ -1181,6 +1207,108 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
 
         // ---- phase B: walk the W*W rows of every selected lane.  branch-free: W row reads, then W
         //      table reads, per j; rows nobody occupies add the table's zero entry.
+        if constexpr (SLAB) {
+        if (sel) {
+            // ---- wide window: per y-slab j the W row masks (phase A) and at once the walk of its W rows
+            //      (phase B); nothing but the per-k sums and the running moments lives from slab to slab.
+            //      (what a lane brings in here is invariant in the pass loop, and what is derived from it
+            //      would be hoisted out of the loop and kept in registers through all of it: opaque copies)
+            double px = qx, py = qy, pz = qz;
+            int32_t gx = hx, gy = hy, gz = hz, sy_ = sgn_y, sz_ = sgn_z, tx_ = tx, ty_ = ty, tz_ = tz;
+            asm volatile("" : "+v"(px), "+v"(py), "+v"(pz), "+v"(gx), "+v"(gy), "+v"(gz), "+v"(sy_), "+v"(sz_),
+                              "+v"(tx_), "+v"(ty_), "+v"(tz_));
+            double dx2[W], dz2[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                double d = px - (tab ? ctab[tx_ + i] : nm_centre(gx + dmin + i, L.min_x, L.edge, L.half_edge));
+                dx2[i] = d * d;
+                d = pz - (tab ? ctab[128 + tz_ + sz_ * (i - C)]
+                              : nm_centre(gz + sz_ * (i - C), L.min_z, L.edge, L.half_edge));
+                dz2[i] = d * d;
+            }
+            const int32_t rx = gx + dmin - ox;
+            const int32_t rhome8 = (__mul24(gz - oz, ey) + (gy - oy)) << 3;
+            const int32_t step_z8 = (sz_ < 0 ? -ey : ey) << 3, step_y8 = sy_ << 3;
+            const unsigned char* rows8 = (const unsigned char*)rows;
+            uint32_t bk[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) bk[i] = 0u;
+            uint32_t n = 0, sx = 0, sxx = 0, sy = 0, syy = 0, sxy = 0, syz = 0;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                double dyj = py - (tab ? ctab[64 + ty_ + sy_ * (j - C)]
+                                       : nm_centre(gy + sy_ * (j - C), L.min_y, L.edge, L.half_edge));
+                dyj = dyj * dyj;
+                double pxy[W];
+#pragma unroll
+                for (int i = 0; i < W; ++i) pxy[i] = dx2[i] + dyj;
+                uint32_t m[RPJ];
+#pragma unroll
+                for (int h = 0; h < RPJ; ++h) m[h] = 0u;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    RowBound rb = RT.rb[j * W + k];
+                    if constexpr (RHO > 0) rb = nm_static_bounds<RHO>().rb[j * W + k];
+                    if (rb.b < 0) continue;
+                    uint32_t outside = 0u;
+#pragma unroll
+                    for (int i = W - 1; i >= 0; --i) {
+                        const int ad = i > C ? i - C : C - i;
+                        if (ad > rb.b) continue;
+                        if (ad <= rb.a) {
+                            outside = outside << 1;
+                        } else {
+                            const double sq = pxy[i] + dz2[k];
+                            const double t = r2 - sq;      // sign bit set  <=>  sq > r^2  (exact)
+                            outside = __builtin_amdgcn_alignbit(outside, (uint32_t)__double2hiint(t), 31);
+                        }
+                    }
+                    const uint32_t span = (1u << (2 * rb.b + 1)) - 1u;
+                    m[k / RPR] |= ((~outside) & span) << ((k % RPR) * W + 2 + (C - rb.b));
+                }
+                uint32_t ajj = 0u, cjj = 0u;
+                uint32_t valid[W];
+                const int32_t base_j = rhome8 + __mul24(j - C, step_y8);
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    if constexpr (RHO > 0)
+                        if (nm_static_bounds<RHO>().rb[j * W + k].b < 0) continue;
+                    const uint64_t row = *(const uint64_t*)(rows8 + (base_j + __mul24(k - C, step_z8)));
+                    const uint32_t in4 = (m[k / RPR] >> ((k % RPR) * W)) & (((1u << W) - 1u) << 2);
+                    valid[k] = (uint32_t)(row >> rx) & in4;      // 4 * (occupied & inside)
+                }
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    if constexpr (RHO > 0)
+                        if (nm_static_bounds<RHO>().rb[j * W + k].b < 0) continue;
+                    const uint32_t t = lut[valid[k] >> 2];
+                    ajj += t;
+                    bk[k] += t;
+                    cjj += (t & 0xFFu) * (uint32_t)k;
+                }
+                const uint32_t na = ajj & 0xFFu, xa = (ajj >> 8) & 0xFFFu, xxa = ajj >> 20;
+                n += na;
+                sx += xa;
+                sxx += xxa;
+                sy += na * j;
+                syy += na * (j * j);
+                sxy += xa * j;
+                syz += cjj * j;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            uint32_t sz = 0, szz = 0, sxz = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const uint32_t nb = bk[i] & 0xFFu, xb = (bk[i] >> 8) & 0xFFFu;
+                sz += nb * i;
+                szz += nb * (i * i);
+                sxz += xb * i;
+            }
+            m_n = n; m_sx = sx; m_sy = sy; m_sz = sz; m_sxx = sxx; m_sxy = sxy; m_sxz = sxz;
+            m_syy = syy; m_syz = syz; m_szz = szz;
+            done = true;
+        }
+        } else
         if (sel) {
             const int32_t rx = hx + dmin - ox;
             // row of the home cell, and the lane's signed strides through the mirrored window
@@ -1202,7 +1330,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                 uint32_t valid[W];
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    if (RHO3 && NM_BOUNDS_RHO3.rb[j * W + k].b < 0) continue;
+                    if constexpr (RHO > 0)
+                        if (nm_static_bounds<RHO>().rb[j * W + k].b < 0) continue;
                     const uint64_t row = *(const uint64_t*)(
                         rows8 + (__mul24(k - C, step_z8) + (rhome8 + __mul24(j - C, step_y8))));
                     const uint32_t in4 = (inside[j * RPJ + k / RPR] >> ((k % RPR) * W)) &
@@ -1211,7 +1340,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                 }
 #pragma unroll
                 for (int k = 0; k < W; ++k) {
-                    if (RHO3 && NM_BOUNDS_RHO3.rb[j * W + k].b < 0) continue;
+                    if constexpr (RHO > 0)
+                        if (nm_static_bounds<RHO>().rb[j * W + k].b < 0) continue;
                     const uint32_t t = lut[valid[k] >> 2];
                     aj[j] += t;
                     bk[k] += t;
@@ -1248,7 +1378,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         }
         lds_fence();
     }
-    if (passes > 1 && lane == 0) atomicAdd(&I.counters[9], passes - 1);
+    if (passes > 1 && lane == 0) atomicAdd(&S->stats[9], passes - 1);
 
     // ---- epilogue: features from the integer moments (features.py:21-57), one query per lane
     const bool emit = have && !far;
@@ -1279,7 +1409,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     }
     const unsigned long long degenerate = __ballot(emit && m_n < 2u);
     if (degenerate && lane == (__ffsll((long long)degenerate) - 1))
-        atomicAdd(&I.counters[8], (uint32_t)__popcll(degenerate));
+        atomicAdd(&S->stats[8], (uint32_t)__popcll(degenerate));
     if (A.sparse) {
         const unsigned long long sparse = __ballot(have && (far || m_n < (uint32_t)A.sparse_k));
         if (lane == 0) A.sparse[(int64_t)s * A.sparse_words + batch] = sparse;
@@ -1339,7 +1469,7 @@ __global__ __launch_bounds__(64) void k_scale_features_generic(ScaleArgs A)
             }
             if (ONLY_UNPRUNED && S->prune_ok) continue;
             bool sp = false;
-            if (have) nm_lane_generic(A, S->L, S->I, S->r2, s, qi, qx, qy, qz, &sp);
+            if (have) nm_lane_generic(A, S->L, S->I, S->stats, S->r2, s, qi, qx, qy, qz, &sp);
             if (A.sparse) {
                 const unsigned long long sparse = __ballot(have && sp);
                 if (threadIdx.x == 0) A.sparse[(int64_t)s * A.sparse_words + batch] = sparse;
@@ -1356,12 +1486,13 @@ __global__ void k_publish_info_all(const ScaleDev* __restrict__ ladder, int32_t 
 {
     const int i = threadIdx.x;
     if (i < n) {
-        const uint32_t* counters = ladder[i].I.counters;
+        const uint32_t* counters = ladder[i].I.counters;      // of the index (a borrowed one: its owner's)
+        const uint32_t* stats = ladder[i].stats;              // of this scale
         // M (-1: the index build timed out or overflowed, or the lattice is not addressable)
         const bool bad = !ladder[i].valid || counters[3] || counters[2];
         info[4 * i + 0] = bad ? -1 : (int64_t)counters[1];
-        info[4 * i + 1] = counters[8];   // neighborhoods with population < 2
-        info[4 * i + 2] = counters[9];   // extra passes of the search kernel
+        info[4 * i + 1] = stats[8];      // neighborhoods with population < 2
+        info[4 * i + 2] = stats[9];      // extra passes of the search kernel
         info[4 * i + 3] = ladder[i].I.hash ? counters[0] : counters[4];   // leaves that hold a voxel
     }
 }
@@ -1632,15 +1763,22 @@ static void launch_table_kernel(const ScaleArgs& A, double rho, int W, int block
     const double rho2 = rho * rho;
     // whether pruning is sound for a lattice is decided on the device (ScaleDev::prune_ok): the tables
     // here are the pruned ones, lattices that cannot use them take the per-lane path inside the kernel
-    const bool rho3 = W == 7 && fabs(rho - 3.0) < 1e-9;
+    const bool whole = fabs(rho - floor(rho + 0.5)) < 1e-9;      // r is a whole number of edges
     switch (W) {
-        case 3: k_scale_features<3, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, true), A.scales, A.F.nodes); break;
-        case 5: k_scale_features<5, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, true), A.scales, A.F.nodes); break;
+        case 3: k_scale_features<3, 0, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<3>(rho2, true), A.scales, A.F.nodes); break;
+        case 5: k_scale_features<5, 0, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<5>(rho2, true), A.scales, A.F.nodes); break;
         case 7:
-            if (rho3) k_scale_features<7, true, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3, A.scales, A.F.nodes);
-            else k_scale_features<7, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, true), A.scales, A.F.nodes);
+            if (whole) k_scale_features<7, 3, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO3, A.scales, A.F.nodes);
+            else k_scale_features<7, 0, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<7>(rho2, true), A.scales, A.F.nodes);
             break;
-        default: k_scale_features<9, false, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, true), A.scales, A.F.nodes); break;
+        case 9:
+            if (whole) k_scale_features<9, 4, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO4, A.scales, A.F.nodes);
+            else k_scale_features<9, 0, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<9>(rho2, true), A.scales, A.F.nodes);
+            break;
+        default:
+            if (whole) k_scale_features<11, 5, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, NM_BOUNDS_RHO5, A.scales, A.F.nodes);
+            else k_scale_features<11, 0, FOREST, LOOP><<<blocks, 64, 0, s>>>(A, nm_make_bounds<11>(rho2, true), A.scales, A.F.nodes);
+            break;
     }
 }
 
@@ -1652,7 +1790,7 @@ static bool launch_scale_kernel(const ScaleArgs& A, double radius, double edge, 
     // that need several passes) better than a persistent grid did (measured: persistent -17 %)
     const int blocks = (int)((A.n_slots + 63) / 64);
     const double rho = radius / edge;
-    if (W == 3 || W == 5 || W == 7 || W == 9) {
+    if (W == 3 || W == 5 || W == 7 || W == 9 || W == 11) {
         // the scales the table kernel has to skip (decided on the device) first: the classifier in the
         // table kernel's epilogue needs every column of the row
         k_scale_features_generic<true><<<blocks < 2048 ? blocks : 2048, 64, 0, s>>>(A);

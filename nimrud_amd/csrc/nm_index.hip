@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
     //      block's distinct words meet in the LDS table and leave as one atomicOr each.
     bool any_dense = false;
     for (int32_t sc = 0; sc < n_scales; ++sc)
-        any_dense = any_dense || (ladder[sc].valid && ladder[sc].I.hash == nullptr);
+        any_dense = any_dense || (ladder[sc].valid && !ladder[sc].shared && ladder[sc].I.hash == nullptr);
     if (any_dense) {
         for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {      // (trip count is block-uniform: barriers)
             const int64_t base = wave_lo + (int64_t)it * 64;
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
             }
 #pragma nounroll
             for (int32_t sc = 0; sc < n_scales; ++sc) {
-                if (!ladder[sc].valid || ladder[sc].I.hash != nullptr) continue;
+                if (!ladder[sc].valid || ladder[sc].shared || ladder[sc].I.hash != nullptr) continue;
                 const LatticeDev L = ladder[sc].L;
                 const IndexDev I = ladder[sc].I;
                 __syncthreads();       // the previous flush has read the table
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
     // ---- pass 2: the scales with a directory (hash form)
 #pragma nounroll
     for (int32_t sc = 0; sc < n_scales; ++sc) {
-        if (!ladder[sc].valid) continue;
+        if (!ladder[sc].valid || ladder[sc].shared) continue;      // (block-uniform)
         const LatticeDev L = ladder[sc].L;
         const IndexDev I = ladder[sc].I;
         const bool dense = I.hash == nullptr;
@@ -1182,10 +1182,17 @@ __global__ __launch_bounds__(64) void k_make_ladder(const double* __restrict__ m
         L.by = L.wy > NM_SBY_BITS ? L.wy - NM_SBY_BITS : 0;
         L.bz = L.wz > NM_SBZ_BITS ? L.wz - NM_SBZ_BITS : 0;
         L.keybits = NM_LOCAL_BITS + L.bx + L.by + L.bz;
-        S.I.hash = P.hash[sc];
-        S.I.leaf = P.leaf[sc];
-        S.I.counters = P.counters[sc];
+        // a scale with the edge length of an earlier one has that scale's lattice: it borrows its index
+        int owner = sc;
+        for (int j = sc - 1; j >= 0; --j)
+            if (P.edge[j] == e) owner = j;
+        S.I.hash = P.hash[owner];
+        S.I.leaf = P.leaf[owner];
+        S.I.counters = P.counters[owner];
         S.I.status = status;
+        S.stats = P.counters[sc];
+        S.shared = owner != sc;
+        S.reserved = 0;
         S.valid = bad ? 0 : 1;
         nm_scale_finish(&S, P.radius[sc], P.hash_capacity, P.leaf_capacity, !bad);
         ladder[sc] = S;
@@ -1204,7 +1211,7 @@ struct LadderPut {
     int32_t n_scales;
     int32_t first;                     // index of P.scale[0] in the device array
     int32_t finest;                    // index (in the device array) of the ordering scale, -1: not here
-    ScaleDev scale[8];
+    ScaleDev scale[8];                 // (stats / shared filled in by the host: nm_ladder_put)
     double radius[8];
     uint32_t hash_capacity[8], leaf_alloc[8];      // slots of the table, leaves the workspace has room for
 };
@@ -1217,6 +1224,7 @@ __global__ void k_put_ladder(LadderPut P, ScaleDev* __restrict__ ladder, OrderDe
         S.valid = 1;
         const uint32_t hmask = S.I.hash_mask, lcap = S.I.leaf_capacity;
         nm_scale_finish(&S, P.radius[t], P.hash_capacity[t], P.leaf_alloc[t], P.allow_dense != 0);
+        S.reserved = 0;
         if (S.I.hash) {
             // the host sized this index exactly: keep its numbers
             S.I.hash_mask = hmask;
@@ -1241,14 +1249,23 @@ int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const dou
         P.first = first;
         P.finest = finest;
         for (int t = 0; t < P.n_scales; ++t) {
+            // same lattice as an earlier scale (same edge, hence same corner and widths): borrow its index
+            int owner = first + t;
+            for (int j = first + t - 1; j >= 0; --j)
+                if (L[j].edge == L[first + t].edge && L[j].min_x == L[first + t].min_x &&
+                    L[j].min_y == L[first + t].min_y && L[j].min_z == L[first + t].min_z &&
+                    L[j].wx == L[first + t].wx && L[j].wy == L[first + t].wy && L[j].wz == L[first + t].wz)
+                    owner = j;
             P.scale[t].L = L[first + t];
-            P.scale[t].I = I[first + t];
+            P.scale[t].I = I[owner];
+            P.scale[t].stats = I[first + t].counters;
+            P.scale[t].shared = owner != first + t;
             P.scale[t].r2 = 0.0;
             P.scale[t].valid = 1;
             P.scale[t].prune_ok = 0;
             P.radius[t] = radii[first + t];
-            P.hash_capacity[t] = I[first + t].hash_mask + 1u;
-            P.leaf_alloc[t] = leaf_alloc ? leaf_alloc : I[first + t].leaf_capacity;
+            P.hash_capacity[t] = I[owner].hash_mask + 1u;
+            P.leaf_alloc[t] = leaf_alloc ? leaf_alloc : I[owner].leaf_capacity;
         }
         k_put_ladder<<<1, 64, 0, s>>>(P, d_ladder, d_order);
     }
@@ -1303,6 +1320,11 @@ __global__ __launch_bounds__(256) void k_index_clear_all(const ScaleDev* __restr
     const IndexDev I = ladder[blockIdx.y].I;
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if (ladder[blockIdx.y].shared) {
+        // a borrowed index is cleared by its owner; the borrower's own counter block holds its statistics
+        if (tid < 64) ladder[blockIdx.y].stats[tid] = 0u;
+        return;
+    }
     if (!I.hash) {
         // dense: every superblock's leaf, zeroed; all of them count as allocated
         uint4* l = (uint4*)I.leaf;
@@ -1322,6 +1344,7 @@ __global__ __launch_bounds__(256) void k_index_clear_all(const ScaleDev* __restr
 __global__ __launch_bounds__(256) void k_count_voxels_all(const ScaleDev* __restrict__ ladder)
 {
     __shared__ uint32_t wsum[4];
+    if (ladder[blockIdx.y].shared) return;       // counted by the owner, into the counters both read
     const IndexDev I = ladder[blockIdx.y].I;
     const uint32_t n_leaves = min(I.counters[0], I.leaf_capacity);
     const uint64_t words = (uint64_t)n_leaves * NM_LEAF_WORDS / 4;     // as uint4

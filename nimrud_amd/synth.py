@@ -135,6 +135,12 @@ CONFIGS = {
                          radii=[0.15, 0.30, 0.60, 1.20, 2.40], morton=0.80),
     "c4_lidar_50m": dict(kind="lidar", n=50_000_000, seed=3, edges=[0.05, 0.10, 0.20, 0.40, 0.80],
                          radii=[0.15, 0.30, 0.60, 1.20, 2.40], knn_min=8),
+    # the reference's own ladder shape on the config 3 cloud: ONE voxel edge, several radii (voxel 0.05, scales
+    # 0.15 / 0.20 / 0.25: nimrud/utils/point_clouds.py:29-35; lists of (voxel, [scales...]):
+    # nimrud/prototypes/apc.py:514-518).  the three scales share one lattice and one occupancy index; their
+    # candidate windows are 7, 9 and 11 cells wide
+    "ref_ladder_10m": dict(kind="scene", n=10_000_000, extent=190.0, n_poles=2000, n_spheres=400,
+                           seed=2, edges=[0.05, 0.05, 0.05], radii=[0.15, 0.20, 0.25], morton=0.80),
     # config 5 = the config 3 cloud (same seed, same points) with five-class labels, classified by the
     # random forest of tests/golden/g6_forest_c5.npz (32 trees, depth <= 12) behind the last scale
     "c5_scene_10m_rf": dict(kind="scene", n=10_000_000, extent=190.0, n_poles=2000, n_spheres=400,

@@ -204,3 +204,71 @@ long nm_oracle_scale(const double* query, long nq, long qstride, const double* s
     free(set.slots);
     return m;
 }
+
+
+/*
+ * the neighbor lists themselves (multiscale.py:103: chunk_tree.query_ball_tree(search_tree, radius)) as voxel
+ * ADDRESSES: for every query the addresses of the occupied voxels whose centre lies within r (inclusive, fp64,
+ * ((dx*dx + dy*dy) + dz*dz) <= r*r), in ascending address order (z outer, x inner).  the caller turns an address
+ * into the reference's search-voxel index with a binary search in the sorted unique address array (np.unique,
+ * geometry.py:150).  two calls: addr_out == NULL fills counts[nq]; then offsets[nq + 1] (exclusive prefix of the
+ * counts) and addr_out[offsets[nq]].  returns the number of occupied voxels M, or -1 on allocation failure.
+ */
+long nm_oracle_neighbors(const double* query, long nq, long qstride, const double* search, long ns, long sstride,
+                         const double* min_corner, double e, const int* widths, double r, int* counts,
+                         const long long* offsets, unsigned long long* addr_out, int threads)
+{
+    const int shifts[2] = {widths[0], widths[0] + widths[1]};
+    uint64_t cap = 64;
+    while (cap < (uint64_t)ns * 2) cap <<= 1;
+    addr_set set;
+    set.slots = (uint64_t*)calloc(cap, sizeof(uint64_t));
+    set.mask = cap - 1;
+    if (!set.slots) return -1;
+    long m = 0;
+    for (long i = 0; i < ns; ++i) {
+        const double* p = search + i * sstride;
+        int64_t cx = (int64_t)floor((p[0] - min_corner[0]) / e);
+        int64_t cy = (int64_t)floor((p[1] - min_corner[1]) / e);
+        int64_t cz = (int64_t)floor((p[2] - min_corner[2]) / e);
+        m += set_insert(&set, (uint64_t)(cx + (cy << shifts[0]) + (cz << shifts[1])));
+    }
+    const double r2 = r * r;
+    const int64_t reach = (int64_t)floor(r / e + 0.5 + 1e-9);
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    (void)threads;
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (long i = 0; i < nq; ++i) {
+        const double* q = query + i * qstride;
+        long k = 0;
+        unsigned long long* out = addr_out ? addr_out + offsets[i] : NULL;
+        double fx = floor((q[0] - min_corner[0]) / e), fy = floor((q[1] - min_corner[1]) / e),
+               fz = floor((q[2] - min_corner[2]) / e);
+        if (fabs(fx) < 4e18 && fabs(fy) < 4e18 && fabs(fz) < 4e18) {
+            int64_t hx = (int64_t)fx, hy = (int64_t)fy, hz = (int64_t)fz;
+            for (int64_t gz = hz - reach; gz <= hz + reach; ++gz) {
+                if (gz < 0 || gz >= ((int64_t)1 << widths[2])) continue;
+                double dz = q[2] - centre(gz, min_corner[2], e);
+                for (int64_t gy = hy - reach; gy <= hy + reach; ++gy) {
+                    if (gy < 0 || gy >= ((int64_t)1 << widths[1])) continue;
+                    double dy = q[1] - centre(gy, min_corner[1], e);
+                    for (int64_t gx = hx - reach; gx <= hx + reach; ++gx) {
+                        if (gx < 0 || gx >= ((int64_t)1 << widths[0])) continue;
+                        double dx = q[0] - centre(gx, min_corner[0], e);
+                        double s = (dx * dx + dy * dy) + dz * dz;
+                        if (!(s <= r2)) continue;
+                        uint64_t addr = (uint64_t)(gx + (gy << shifts[0]) + (gz << shifts[1]));
+                        if (!set_has(&set, addr)) continue;
+                        if (out) out[k] = addr;
+                        ++k;
+                    }
+                }
+            }
+        }
+        if (counts) counts[i] = (int)k;
+    }
+    free(set.slots);
+    return m;
+}

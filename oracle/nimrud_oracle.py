@@ -387,8 +387,44 @@ def _c_oracle():
             ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_void_p, ctypes.c_long,
             ctypes.c_long, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
             ctypes.c_void_p, ctypes.c_int]
+        lib.nm_oracle_neighbors.restype = ctypes.c_long
+        lib.nm_oracle_neighbors.argtypes = [
+            ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_void_p, ctypes.c_long,
+            ctypes.c_long, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_double,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _C_ORACLE = lib
     return _C_ORACLE
+
+
+def neighbor_lists_c(query_cloud, search_cloud, edge_length, radius, threads=0, bounds=None):
+    """the neighbor index lists of multiscale.py:103 for ALL queries, as CSR (offsets int64[Nq + 1], index
+    int64[total]): oracle/lattice_oracle.c enumerates, per query, the addresses of the occupied voxels within
+    the radius (hash set of addresses, fp64 inclusive test, ascending address order); an address becomes the
+    reference's search-voxel index by its rank in the sorted unique address array (np.unique,
+    geometry.py:150).  fast enough for a million queries; pinned against the golden neighbor lists captured
+    from the reference (tests/test_oracle.py)."""
+    query = np.ascontiguousarray(np.asarray(query_cloud, dtype=np.float64))
+    search = np.ascontiguousarray(np.asarray(search_cloud, dtype=np.float64))
+    lattice = Lattice(search[:, :3], edge_length, bounds=bounds)
+    mc = np.ascontiguousarray(lattice.minimum_corner, dtype=np.float64)
+    widths = np.ascontiguousarray(lattice.widths, dtype=np.int32)
+    nq = query.shape[0]
+    counts = np.zeros(nq, dtype=np.int32)
+    lib = _c_oracle()
+    args = (query.ctypes.data, nq, query.shape[1], search.ctypes.data, search.shape[0], search.shape[1],
+            mc.ctypes.data, float(edge_length), widths.ctypes.data, float(radius))
+    if lib.nm_oracle_neighbors(*args, counts.ctypes.data, None, None, int(threads)) < 0:
+        raise MemoryError("lattice_oracle: allocation failed")
+    offsets = np.zeros(nq + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    addr = np.zeros(max(int(offsets[-1]), 1), dtype=np.uint64)
+    if lib.nm_oracle_neighbors(*args, None, offsets.ctypes.data, addr.ctypes.data, int(threads)) < 0:
+        raise MemoryError("lattice_oracle: allocation failed")
+    addr = addr[:int(offsets[-1])]
+    unique = lattice.unique_addresses(search[:, :3]).astype(np.uint64)
+    index = np.searchsorted(unique, addr).astype(np.int64)
+    assert np.array_equal(unique[index], addr)
+    return offsets, index
 
 
 def one_scale_c(query_cloud, search_cloud, edge_length, radius, threads=0, bounds=None,

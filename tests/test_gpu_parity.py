@@ -266,6 +266,23 @@ def test_neighbor_lists_against_oracle():
     assert np.array_equal(feats[:, 0], np.diff(off))
 
 
+def test_config2_neighbor_indices_bit_exact_for_every_query():
+    """north_star: "neighbor indices bit-exact".  config 2 at its stated size, finest scale (e = 0.10, r = 0.30):
+    the index lists of ALL 10^6 queries - multiscale.neighbor_lists, i.e. nm_voxelize + nm_scale_neighbors
+    through the C ABI - against the C oracle's enumeration ranked in the sorted unique addresses (np.unique,
+    geometry.py:150; the oracle is pinned on the reference's captured lists in tests/test_oracle.py):
+    offsets and indices equal, element for element."""
+    pts, _, edges, radii = synth.make_config("c2_scene_1m")
+    dev = torch.from_numpy(pts).cuda()
+    off, idx = multiscale.neighbor_lists(dev, dev, edges[0], radii[0])
+    want_off, want_idx = oracle.neighbor_lists_c(pts, pts, edges[0], radii[0])
+    assert np.array_equal(off.cpu().numpy(), want_off)
+    assert idx.shape[0] == want_idx.shape[0] and np.array_equal(idx.cpu().numpy(), want_idx)
+    # and the fused kernel's population is the length of those lists
+    f = multiscale.process_gpu(dev, dev, edges[:1], radii[:1])
+    assert np.array_equal(f[:, 0].cpu().numpy(), np.diff(want_off).astype(np.float64))
+
+
 def test_forest_on_gpu_features():
     from sklearn.ensemble import RandomForestClassifier
     pts, labels = synth.scene_cloud(30000, extent=10.0, n_poles=8, n_spheres=3, seed=81)
@@ -1006,6 +1023,37 @@ def test_config3_full_size_properties():
     for s, (e, r) in enumerate(zip(edges, radii)):
         want_s = oracle.one_scale_c(pts, pts, e, r)
         assert_features_close(f[:, 4 * s:4 * s + 4], want_s, pts)
+
+
+def test_reference_ladder_shape_one_edge_three_radii():
+    """the reference's own ladders: one voxel edge, several radii (point_clouds.py:29-35: voxel 0.05, scales
+    0.15 / 0.20 / 0.25).  the three scales share one lattice, hence ONE occupancy index (built once, ScaleDev::
+    shared), and run on the W = 7, 9 and 11 instances of the table kernel.  every row of every scale against the
+    plain-C oracle: populations bit-exact, features within the contract; and against the same scales computed one
+    call each (own index each): bit-identical."""
+    cfg = synth.CONFIGS["ref_ladder_10m"]
+    pts, _, edges, radii = synth.make_config("ref_ladder_10m", n=1_500_000)
+    assert edges == cfg["edges"] and len(set(edges)) == 1
+    dev = torch.from_numpy(pts).cuda()
+    full, info = multiscale.process_gpu(dev, dev, edges, radii, return_info=True)
+    f = full.cpu().numpy()
+    m = len(np.unique(oracle.Lattice(pts, edges[0]).coordinate_to_address(pts)))
+    assert [i.voxels for i in info] == [m, m, m]
+    for s, (e, r) in enumerate(zip(edges, radii)):
+        want_s = oracle.one_scale_c(pts, pts, e, r)
+        assert np.array_equal(f[:, 4 * s], want_s[:, 0])
+        assert_features_close(f[:, 4 * s:4 * s + 4], want_s, pts)
+        alone = multiscale.process_gpu(dev, dev, [e], [r])
+        assert torch.equal(alone, full[:, 4 * s:4 * s + 4])
+    # mixed ladders: equal edges need not be adjacent, and a finer scale may follow
+    edges2, radii2 = [0.1, 0.05, 0.1, 0.05], [0.3, 0.2, 0.5, 0.15]
+    sub = dev[:300000].contiguous()
+    mixed, info2 = multiscale.process_gpu(sub, sub, edges2, radii2, return_info=True)
+    assert info2[0].voxels == info2[2].voxels and info2[1].voxels == info2[3].voxels
+    for s, (e, r) in enumerate(zip(edges2, radii2)):
+        assert torch.equal(multiscale.process_gpu(sub, sub, [e], [r]), mixed[:, 4 * s:4 * s + 4])
+    host = sub.cpu().numpy()
+    assert_features_close(mixed.cpu().numpy(), oracle.process_c(host, host, edges2, radii2), host)
 
 
 def test_index_timeout_is_sticky_and_never_silent(tmp_path):

@@ -118,6 +118,13 @@ def test_oracle_neighbors_match_reference(golden, name):
             o2, i2 = oracle.neighbors_to_csr(lists)
             assert np.array_equal(o2, off)
             assert np.array_equal(i2, idx)
+        # the C restatement's enumeration (what the full-size index test on the GPU box checks against): the
+        # same lists, for the queries the reference's capture holds; and for ALL queries against the kd-tree
+        o3, i3 = oracle.neighbor_lists_c(pts[:n], pts, e, r)
+        assert np.array_equal(o3, off) and np.array_equal(i3, idx)
+        o4, i4 = oracle.neighbor_lists_c(pts, pts, e, r)
+        o5, i5 = oracle.neighbors_to_csr(oracle.ball_neighbors_kdtree(pts, voxels, r))
+        assert np.array_equal(o4, o5) and np.array_equal(i4, i5)
 
 
 @pytest.mark.parametrize("name", PIPELINE_FIXTURES)

@@ -6,9 +6,9 @@
 // the search kernel (k_scale_features) is bound by vector-ALU issue; its roofline in bench.py needs the price
 // of an instruction of each class of its mix - measured here, not assumed.  every probe is a loop of 64
 // INDEPENDENT instructions of one class (eight rotating destination registers, sources that are never
-// written), TRIPS trips; a launch puts exactly `w` such waves on every SIMD of the chip (one block of 256*w
-// threads per CU for w <= 4, two blocks of 128*w above that, 64 KB of LDS each so that no third block fits)
-// and  time of the launch x maximum clock / (w x instructions per wave)  is the cost of one wave64
+// written), TRIPS trips; a launch puts `w` such waves on every SIMD of the chip the way the search kernel does -
+// one-wave workgroups, 4 w of them per CU, each asking for 160 KB / (4 w) of LDS so that no more fit - and
+// time of the launch x maximum clock / (w x instructions per wave)  is the cost of one wave64
 // instruction in SIMD cycles.  (the clock held under load can be below the maximum: the figures are upper
 // bounds; what matters is the ratio between classes and between columns.)
 // mixed probes interleave two classes one to one: do their costs add (one issue port) or overlap?
@@ -42,8 +42,9 @@ constexpr int PER_TRIP = 64;
         float f0 = a0, f1 = a1, f2 = a2, f3 = a3, f4 = a4, f5 = a5, f6 = a6, f7 = a7;                    \
         float g0 = 1.0001f, g1 = 0.9999f;                                                               \
         uint64_t q0 = a0, q1 = a1, q2 = a2, q3 = a3, q4 = a4, q5 = a5, q6 = a6, q7 = a7;                 \
-        uint32_t la = (threadIdx.x & 63) * 8;                                                           \
-        ((uint64_t*)lds)[threadIdx.x] = a0;                                                             \
+        uint32_t la = (threadIdx.x & 63) * 8, la4 = (threadIdx.x & 63) * 4;                             \
+        const unsigned long long lanes = 0x5555555555555555ull + seed;                                  \
+        ((uint64_t*)lds)[threadIdx.x & 63] = a0;                                                             \
         __syncthreads();                                                                                \
         _Pragma("nounroll") for (int t = 0; t < TRIPS; ++t) {                                           \
             BODY                                                                                        \
@@ -69,8 +70,26 @@ constexpr int PER_TRIP = 64;
 #define I_LSHL_ADD(N) asm volatile("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(a##N) : "v"(s0), "v"(s1));
 #define I_ADD3(N) asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(a##N) : "v"(s0), "v"(s1), "v"(s2));
 #define I_MOV(N) asm volatile("v_mov_b32 %0, %1" : "=v"(a##N) : "v"(s0));
-#define I_CNDMASK(N) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a##N) : "v"(s0), "v"(s1) : "vcc");
+#define I_CNDMASK(N) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(a##N) : "v"(s0), "v"(s1), "s"(lanes));
 #define I_BFE(N) asm volatile("v_bfe_u32 %0, %1, 8, 12" : "=v"(a##N) : "v"(s0));
+#define I_OR(N) asm volatile("v_or_b32 %0, %1, %2" : "=v"(a##N) : "v"(s0), "v"(s1));
+#define I_SUB_U32(N) asm volatile("v_sub_u32 %0, %1, %2" : "=v"(a##N) : "v"(s0), "v"(s1));
+#define I_MIN_U32(N) asm volatile("v_min_u32 %0, %1, %2" : "=v"(a##N) : "v"(s0), "v"(s1));
+#define I_MAX_I32(N) asm volatile("v_max_i32 %0, %1, %2" : "=v"(a##N) : "v"(s0), "v"(s1));
+#define I_AND_OR(N) asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a##N) : "v"(s0), "v"(s1), "v"(s2));
+#define I_LSHL_OR(N) asm volatile("v_lshl_or_b32 %0, %1, 3, %2" : "=v"(a##N) : "v"(s0), "v"(s1));
+#define I_PERM(N) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a##N) : "v"(s0), "v"(s1), "v"(s2));
+#define I_BCNT(N) asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(a##N) : "v"(s0), "v"(s1));
+#define I_BFREV(N) asm volatile("v_bfrev_b32 %0, %1" : "=v"(a##N) : "v"(s0));
+#define I_ADDC(N) asm volatile("v_addc_co_u32 %0, vcc, %1, %2, vcc" : "=v"(a##N) : "v"(s0), "v"(s1) : "vcc");
+#define I_MUL_U24(N) asm volatile("v_mul_u32_u24 %0, %1, %2" : "=v"(a##N) : "v"(s0), "v"(s1));
+#define I_CVT_I32_F64(N) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(a##N) : "v"(e0));
+#define I_FLOOR_F64(N) asm volatile("v_floor_f64 %0, %1" : "=v"(d##N) : "v"(e0));
+#define I_MIN_F64(N) asm volatile("v_min_f64 %0, %1, %2" : "=v"(d##N) : "v"(e0), "v"(e1));
+#define I_MIN_F32_PLAIN(N) asm volatile("v_min_f32 %0, %1, %2" : "=v"(f##N) : "v"(g0), "v"(g1));
+#define I_RSQ_F64(N) asm volatile("v_rsq_f64 %0, %1" : "=v"(d##N) : "v"(e0));
+#define I_RCP_F32(N) asm volatile("v_rcp_f32 %0, %1" : "=v"(f##N) : "v"(g0));
+#define I_DS_READ_B32_NC(N) asm volatile("ds_read_b32 %0, %1" : "=v"(a##N) : "v"(la4));
 #define I_LSHR_B64(N) asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(q##N) : "v"(s2), "v"(q##N));
 #define I_ADD_F64(N) asm volatile("v_add_f64 %0, %1, %2" : "=v"(d##N) : "v"(e0), "v"(e1));
 #define I_MUL_F64(N) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(d##N) : "v"(e0), "v"(e1));
@@ -109,6 +128,24 @@ PROBE_KERNEL(p_mov, SIXTYFOUR(I_MOV))
 PROBE_KERNEL(p_cndmask, SIXTYFOUR(I_CNDMASK))
 PROBE_KERNEL(p_bfe, SIXTYFOUR(I_BFE))
 PROBE_KERNEL(p_lshr_b64, SIXTYFOUR(I_LSHR_B64))
+PROBE_KERNEL(p_or, SIXTYFOUR(I_OR))
+PROBE_KERNEL(p_sub_u32, SIXTYFOUR(I_SUB_U32))
+PROBE_KERNEL(p_min_u32, SIXTYFOUR(I_MIN_U32))
+PROBE_KERNEL(p_max_i32, SIXTYFOUR(I_MAX_I32))
+PROBE_KERNEL(p_and_or, SIXTYFOUR(I_AND_OR))
+PROBE_KERNEL(p_lshl_or, SIXTYFOUR(I_LSHL_OR))
+PROBE_KERNEL(p_perm, SIXTYFOUR(I_PERM))
+PROBE_KERNEL(p_bcnt, SIXTYFOUR(I_BCNT))
+PROBE_KERNEL(p_bfrev, SIXTYFOUR(I_BFREV))
+PROBE_KERNEL(p_addc, SIXTYFOUR(I_ADDC))
+PROBE_KERNEL(p_mul_u24, SIXTYFOUR(I_MUL_U24))
+PROBE_KERNEL(p_cvt_i32_f64, SIXTYFOUR(I_CVT_I32_F64))
+PROBE_KERNEL(p_floor_f64, SIXTYFOUR(I_FLOOR_F64))
+PROBE_KERNEL(p_min_f64, SIXTYFOUR(I_MIN_F64))
+PROBE_KERNEL(p_min_f32_plain, SIXTYFOUR(I_MIN_F32_PLAIN))
+PROBE_KERNEL(p_rsq_f64, SIXTYFOUR(I_RSQ_F64))
+PROBE_KERNEL(p_rcp_f32, SIXTYFOUR(I_RCP_F32))
+PROBE_KERNEL(p_ds_read_b32_nc, SIXTYFOUR(I_DS_READ_B32_NC) WAITLDS)
 PROBE_KERNEL(p_add_f64, SIXTYFOUR(I_ADD_F64))
 PROBE_KERNEL(p_mul_f64, SIXTYFOUR(I_MUL_F64))
 PROBE_KERNEL(p_fma_f64, SIXTYFOUR(I_FMA_F64))
@@ -172,24 +209,30 @@ int main(int argc, char** argv)
         {"v_add_u32", p_add_u32, 64}, {"v_alignbit_b32 (imm)", p_alignbit, 64}, {"v_alignbit_b32 (vgpr shift)", p_alignbit_v, 64},
         {"v_bitop3_b32", p_bitop3, 64}, {"v_mad_u32_u24", p_mad_u24, 64}, {"v_mul_lo_u32", p_mul_lo, 64},
         {"v_and_b32", p_and, 64}, {"v_lshlrev_b32", p_lshl, 64}, {"v_lshl_add_u32", p_lshl_add, 64}, {"v_add3_u32", p_add3, 64},
-        {"v_mov_b32", p_mov, 64}, {"v_cndmask_b32", p_cndmask, 64}, {"v_bfe_u32", p_bfe, 64}, {"v_lshrrev_b64", p_lshr_b64, 64},
+        {"v_mov_b32", p_mov, 64}, {"v_cndmask_b32 (sgpr mask)", p_cndmask, 64}, {"v_bfe_u32", p_bfe, 64}, {"v_lshrrev_b64", p_lshr_b64, 64},
+        {"v_or_b32", p_or, 64}, {"v_sub_u32", p_sub_u32, 64}, {"v_min_u32", p_min_u32, 64}, {"v_max_i32", p_max_i32, 64},
+        {"v_and_or_b32", p_and_or, 64}, {"v_lshl_or_b32", p_lshl_or, 64}, {"v_perm_b32", p_perm, 64}, {"v_bcnt_u32_b32", p_bcnt, 64},
+        {"v_bfrev_b32", p_bfrev, 64}, {"v_addc_co_u32", p_addc, 64}, {"v_mul_u32_u24", p_mul_u24, 64},
+        {"v_cvt_i32_f64", p_cvt_i32_f64, 64}, {"v_floor_f64", p_floor_f64, 64}, {"v_min_f64", p_min_f64, 64},
+        {"v_min_f32", p_min_f32_plain, 64}, {"v_rsq_f64", p_rsq_f64, 64}, {"v_rcp_f32", p_rcp_f32, 64},
+        {"ds_read_b32 (4-byte stride: conflict-free)", p_ds_read_b32_nc, 64},
         {"v_add_f64", p_add_f64, 64}, {"v_mul_f64", p_mul_f64, 64}, {"v_fma_f64", p_fma_f64, 64}, {"v_rcp_f64", p_rcp_f64, 64},
         {"v_cvt_f64_u32", p_cvt_f64_u32, 64}, {"v_cvt_f32_f64", p_cvt_f32_f64, 64}, {"v_cmp_lt_f64", p_cmp_f64, 64},
         {"v_cmp_lt_f32", p_cmp_f32, 64}, {"v_add_f32", p_add_f32, 64}, {"v_fma_f32", p_fma_f32, 64}, {"v_min_f32 |abs|", p_min_f32, 64},
         {"v_pk_add_f32", p_pk_add_f32, 64}, {"v_pk_mul_f32", p_pk_mul_f32, 64}, {"v_pk_fma_f32", p_pk_fma_f32, 64},
-        {"ds_read_b64", p_ds_read_b64, 64}, {"ds_read_b32", p_ds_read_b32, 64}, {"v_readlane_b32", p_readlane, 64},
+        {"ds_read_b64", p_ds_read_b64, 64}, {"ds_read_b32 (8-byte stride: 2-way conflict)", p_ds_read_b32, 64}, {"v_readlane_b32", p_readlane, 64},
         {"v_min_i32_dpp", p_dpp_min, 64}, {"chain v_add_u32 (dependent)", p_chain_u32, 64}, {"chain v_add_f64 (dependent)", p_chain_f64, 64},
         {"mix v_add_f64 + v_add_u32", p_mix_f64_u32, 64}, {"mix v_add_f64 + v_alignbit", p_mix_f64_alignbit, 64},
         {"mix v_add_f64 + v_add_f32", p_mix_f64_f32, 64}, {"mix v_add_u32 + v_add_f32", p_mix_u32_f32, 64},
         {"mix v_add_f64 + ds_read_b64", p_mix_f64_ds, 64}, {"mix v_add_u32 + ds_read_b64", p_mix_u32_ds, 64},
         {"test: add_f64, sub_f64, alignbit (x64)", p_test_f64, 192},
     };
-    const int waves_per_simd[] = {1, 2, 4, 5, 8};
+    const int waves_per_simd[] = {1, 2, 3, 4, 5, 8};
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     FILE* jf = json_path ? fopen(json_path, "w") : nullptr;
-    if (jf) fprintf(jf, "{\n \"device\": \"%s\", \"cus\": %d, \"max_clock_mhz\": %d,\n \"unit\": \"SIMD cycles per wave64 instruction at the maximum clock (time of the launch x max clock / (waves per SIMD x instructions per wave)); the clock held under load can be lower, so these are upper bounds - compare classes within a column\",\n \"waves_per_simd\": [1, 2, 4, 5, 8],\n \"cycles\": {\n", prop.name, cus, clock_khz / 1000);
+    if (jf) fprintf(jf, "{\n \"device\": \"%s\", \"cus\": %d, \"max_clock_mhz\": %d,\n \"unit\": \"SIMD cycles per wave64 instruction at the maximum clock (time of the launch x max clock / (waves per SIMD x instructions per wave)); the clock held under load can be lower, so these are upper bounds - compare classes within a column\",\n \"waves_per_simd\": [1, 2, 3, 4, 5, 8],\n \"cycles\": {\n", prop.name, cus, clock_khz / 1000);
     printf("%-44s", "class \\ waves per SIMD");
     for (int w : waves_per_simd) printf(" %7d", w);
     printf("   (SIMD cycles per wave-instruction at max clock)\n");
@@ -200,10 +243,10 @@ int main(int argc, char** argv)
         first = false;
         bool firstw = true;
         for (int w : waves_per_simd) {
-            // w waves on every SIMD: w <= 4 one block of 256*w threads per CU; above, two blocks of 128*w
-            const int blocks_per_cu = w <= 4 ? 1 : 2;
-            const int threads = 256 * w / blocks_per_cu;
-            const size_t lds = 65536;       // 2 blocks of 64 KB fit a CU's 160 KB, a third does not
+            // w waves on every SIMD: one-wave workgroups, 4 w per CU, LDS sized so that no more fit
+            const int blocks_per_cu = 4 * w;
+            const int threads = 64;
+            const size_t lds = (size_t)(160 * 1024 / blocks_per_cu) / 1024 * 1024;
             CHECK(hipFuncSetAttribute((const void*)p.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             float best = 1e30f;
             for (int rep = 0; rep < 4; ++rep) {
