@@ -39,12 +39,13 @@ extern "C" int nm_create(nm_ctx** out, int device)
     ctx = new nm_ctx();
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
-    // the sticky status words: the only memory the library owns (256 B on the device, 256 B pinned)
-    NM_CREATE_TRY(hipMalloc((void**)&ctx->d_status, NM_ST_WORDS * 4));
-    NM_CREATE_TRY(hipMemset(ctx->d_status, 0, NM_ST_WORDS * 4));
-    NM_CREATE_TRY(hipHostMalloc((void**)&ctx->h_status, NM_ST_WORDS * 4, hipHostMallocDefault));
-    NM_CREATE_TRY(hipEventCreateWithFlags(&ctx->status_event, hipEventDisableTiming));
+    // the sticky status words: the only memory the library owns - 256 B of pinned host memory that the kernels
+    // see through its device address.  a kernel writes there only when something is wrong, so nothing has to
+    // be copied back after a call (the copy of a device-side block was a 5 us kernel behind every step)
+    NM_CREATE_TRY(hipHostMalloc((void**)&ctx->h_status, NM_ST_WORDS * 4, hipHostMallocMapped));
     for (int i = 0; i < NM_ST_WORDS; ++i) ctx->h_status[i] = 0u;
+    NM_CREATE_TRY(hipHostGetDevicePointer((void**)&ctx->d_status, ctx->h_status, 0));
+    NM_CREATE_TRY(hipEventCreateWithFlags(&ctx->status_event, hipEventDisableTiming));
     *out = ctx;
     return NM_OK;
 }
@@ -58,12 +59,9 @@ extern "C" int nm_create(nm_ctx** out, int device)
 void nm_status_snapshot(nm_ctx* ctx, hipStream_t s)
 {
     if (!ctx->d_status) return;
-    if (hipMemcpyAsync(ctx->h_status, ctx->d_status, NM_ST_WORDS * 4, hipMemcpyDeviceToHost, s) !=
-        hipSuccess)
-        return;
-    // inside a hipGraph capture the copy becomes a node of the graph - every replay refreshes the mirror -
-    // and no event is recorded (querying a captured event is illegal): nm_check(ctx, 1) after the caller has
-    // synchronised the replay reads the mirror as it stands
+    // the status words live in host memory: what is left to do behind a call is to mark its end.  inside a
+    // hipGraph capture no event is recorded (querying a captured event is illegal): nm_check(ctx, 1) after the
+    // caller has synchronised the replay reads the words as they stand
     if (nm_capturing(s)) return;
     if (hipEventRecord(ctx->status_event, s) == hipSuccess) ctx->status_pending = true;
 }
@@ -81,8 +79,7 @@ int nm_status_poll(nm_ctx* ctx, bool wait)
     } else if (!wait) {
         return NM_OK;              // nothing outstanding that this call could know about
     }
-    // (wait without a pending event: the caller has synchronised a graph replay; its copy node has
-    // refreshed the mirror)
+    // (wait without a pending event: the caller has synchronised a graph replay)
     const uint32_t* st = ctx->h_status;
     if (st[NM_ST_LATTICE]) {
         switch (st[NM_ST_LATTICE]) {
@@ -118,7 +115,6 @@ extern "C" int nm_clear_error(nm_ctx* ctx)
     nm_device_guard guard(ctx->device);
     // outstanding work may still set a word: drain the device first, then start clean
     NM_HIP(ctx, hipDeviceSynchronize());
-    NM_HIP(ctx, hipMemset(ctx->d_status, 0, NM_ST_WORDS * 4));
     for (int i = 0; i < NM_ST_WORDS; ++i) ctx->h_status[i] = 0u;
     ctx->status_pending = false;
     ctx->sticky = 0;
@@ -131,8 +127,7 @@ extern "C" void nm_destroy(nm_ctx* ctx)
     if (!ctx) return;
     nm_device_guard guard(ctx->device);
     if (ctx->status_event) (void)hipEventDestroy(ctx->status_event);
-    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
-    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);      // (d_status is its device address)
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->sync_events) (void)hipEventDestroy(e);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);

@@ -9,9 +9,9 @@
 
 #include "../../include/nimrud_hip.h"
 
-// sticky device-side status (nm_ctx::d_status, 64 words).  kernels only ever set words; the host reads a
-// snapshot that every feature call leaves behind (async copy to pinned memory + event) and turns a
-// non-zero word into NM_ERR_HIP / NM_ERR_LATTICE on the NEXT call or in nm_check - never a silent result.
+// sticky status (nm_ctx::h_status / d_status, 64 words of device-mapped host memory).  kernels only ever set
+// words; every feature call leaves an event behind, and the host turns a non-zero word into NM_ERR_HIP /
+// NM_ERR_LATTICE on the NEXT call or in nm_check - never a silent result.
 enum {
     NM_ST_INDEX_TIMEOUT = 0,   // the index builder's bounded wait for a leaf number ran out
     NM_ST_LEAF_OVERFLOW = 1,   // more occupied superblocks than the workspace has leaves for
@@ -44,9 +44,9 @@ struct nm_ctx {
     int device;
     std::string error;
     int num_cus;
-    uint32_t* d_status = nullptr;       // device, NM_ST_WORDS words, zero = healthy
-    uint32_t* h_status = nullptr;       // pinned host mirror of the last snapshot
-    hipEvent_t status_event = nullptr;  // completion of the last snapshot copy
+    uint32_t* h_status = nullptr;       // pinned, device-mapped host memory, NM_ST_WORDS words, zero = healthy
+    uint32_t* d_status = nullptr;       // its device address: what the kernels write through
+    hipEvent_t status_event = nullptr;  // end of the last feature call
     bool status_pending = false;
     int sticky = 0;                     // a past asynchronous failure: every later call returns it
     // stage timing (nm_profile_begin/end): events[4*k .. 4*k+3] bracket the three stages of call k
@@ -263,7 +263,8 @@ struct OrderDev {
     int32_t morton;          // 1: compact Z-order key, 0: superblock key (some width above 21 bits)
     int32_t shift;           // low key bits dropped so that the key fits NM_ORDER_KEY_BITS
     int32_t valid;
-    int32_t bpp;             // key bits per radix pass: ceil(key bits / 3), at most NM_ORDER_PASS_BITS
+    int32_t bpp;             // key bits per radix pass: ceil(key bits / passes), at most NM_ORDER_PASS_BITS
+    int32_t passes;          // 2 for keys of at most 2 * NM_ORDER_PASS_BITS bits, else 3
 };
 
 // bits of the spatial order's sort key (a wider key loses its low bits): three radix passes of at most 10 bits.
@@ -300,7 +301,8 @@ __host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O)
     const int bits = O->morton ? L.wx + L.wy + L.wz : L.keybits;
     O->shift = bits > NM_ORDER_KEY_BITS ? bits - NM_ORDER_KEY_BITS : 0;
     const int kept = bits - O->shift;
-    int bpp = (kept + 2) / 3;
+    O->passes = kept <= 2 * NM_ORDER_PASS_BITS ? 2 : 3;
+    int bpp = (kept + O->passes - 1) / O->passes;
     if (bpp < 1) bpp = 1;
     if (bpp > NM_ORDER_PASS_BITS) bpp = NM_ORDER_PASS_BITS;
     O->bpp = bpp;

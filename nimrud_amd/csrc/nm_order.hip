@@ -21,16 +21,25 @@
 //     count matrix, then a scatter kernel with no inter-block dependency at all.  a step can be captured in a
 //     hipGraph and replayed back to back (the library's look-back state was the suspect when that stalled).
 //
-// per pass: tiles of SORT_TILE = 8192 pairs, 512 threads, 72 KB of LDS (two blocks per CU); a tile's pairs are
-// ranked, placed in digit order in LDS and leave as runs of consecutive addresses.  blocks are mapped to tiles
-// so that each XCD owns one contiguous range of tiles: the short runs of neighbouring tiles meet in one L2.
+// per pass: tiles of 8192 pairs (2048 for clouds of up to 2^20 points), 512 threads, 68 KB of LDS (two blocks per
+// CU); a tile's pairs are ranked, placed in digit order in LDS and leave as runs of consecutive addresses.
+// blocks are mapped to tiles so that each XCD owns one contiguous range of tiles: the short runs of neighbouring
+// tiles meet in one L2.  small clouds: up to 64 tiles the scatter blocks sum the count matrix themselves (no scan
+// launches), and a key of at most 20 bits is sorted in two passes (the third pass's launches leave at once - the
+// host cannot know the key width, the lattice is built on the device).
 
 #include "nm_common.h"
 #include "nm_index.h"
 
 constexpr int SORT_THREADS = 512;
-constexpr int SORT_ITEMS = 16;
-constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;      // 8192 pairs, 64 KB of LDS
+constexpr int SORT_ITEMS_BIG = 16;        // tiles of 8192 pairs: clouds above SORT_SMALL_N points
+constexpr int SORT_ITEMS_SMALL = 4;       // tiles of 2048 pairs: small clouds, where 13 blocks of 8192 pairs leave
+                                          // the chip empty (100 k points: 49 blocks instead of 13)
+constexpr int64_t SORT_SMALL_N = 1 << 20;
+constexpr int SORT_DIRECT_TILES = 64;     // up to this many tiles a scatter block sums the count matrix itself:
+                                          // no scan launches (six of a step's launches, ~5 us each).  (measured
+                                          // at 153 tiles of 8192: every block reading 0.6 MB of counts costs
+                                          // 75 us more than the scans it saves)
 constexpr int SORT_BINS = 1 << NM_ORDER_PASS_BITS;        // 1024
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
@@ -101,29 +110,27 @@ __device__ __forceinline__ uint32_t nm_order_key(const double* __restrict__ p, c
 }
 
 // ---- pass 0, first half: keys, and the digit counts of every tile of the key stream ---------------------------
-// counts are kept digit-major, H[digit * tiles + tile]: a flat exclusive scan of H then IS the table of global
-// offsets (all of digit 0's tiles, then digit 1's, ...)
+// counts are kept digit-major, H[digit * hstride + tile] (hstride = tiles rounded up to four; the padding stays
+// zero): a flat exclusive scan of H then IS the table of global offsets (all of digit 0's tiles, then digit 1's, ...)
+template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_order_keys_hist(const double* __restrict__ xyz, int64_t n,
                                                                   int64_t stride,
                                                                   const OrderDev* __restrict__ od,
                                                                   uint32_t* __restrict__ keys,
-                                                                  uint32_t* __restrict__ H, int32_t tiles)
+                                                                  uint32_t* __restrict__ H, int32_t hstride)
 {
+    constexpr int TILE = SORT_THREADS * ITEMS;
     __shared__ uint32_t lh[SORT_BINS];
     const int tid = threadIdx.x;
-#ifdef NM_KEYS_REVERSED
-    const int32_t tile = tiles - 1 - (int32_t)blockIdx.x;
-#else
     const int32_t tile = blockIdx.x;
-#endif
     lh[tid] = 0u;
     lh[tid + SORT_THREADS] = 0u;
     __syncthreads();
     const OrderDev& O = *od;
     const uint32_t mask = (1u << O.bpp) - 1u;
-    const int64_t base = (int64_t)tile * SORT_TILE;
+    const int64_t base = (int64_t)tile * TILE;
 #pragma unroll 4
-    for (int i = 0; i < SORT_ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * SORT_THREADS + tid;
         if (idx < n) {
             const uint32_t k = nm_order_key(xyz + idx * stride, O);
@@ -132,15 +139,23 @@ __global__ __launch_bounds__(SORT_THREADS) void k_order_keys_hist(const double* 
         }
     }
     __syncthreads();
-    H[(size_t)tid * tiles + tile] = lh[tid];
-    H[(size_t)(tid + SORT_THREADS) * tiles + tile] = lh[tid + SORT_THREADS];
+    H[(size_t)tid * hstride + tile] = lh[tid];
+    H[(size_t)(tid + SORT_THREADS) * hstride + tile] = lh[tid + SORT_THREADS];
+    if (tile == (int32_t)gridDim.x - 1)       // the padding columns of every row (the scan runs in place)
+        for (int32_t pad = (int32_t)gridDim.x; pad < hstride; ++pad) {
+            H[(size_t)tid * hstride + pad] = 0u;
+            H[(size_t)(tid + SORT_THREADS) * hstride + pad] = 0u;
+        }
 }
 
 // ---- passes 1, 2, first half: digit counts of every tile of a pair stream ------------------------------------------
+template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint2* __restrict__ pairs, int64_t n,
                                                             int pass, const OrderDev* __restrict__ od,
-                                                            uint32_t* __restrict__ H, int32_t tiles)
+                                                            uint32_t* __restrict__ H, int32_t hstride)
 {
+    constexpr int TILE = SORT_THREADS * ITEMS;
+    if (pass >= od->passes) return;       // a short key is sorted in two passes: the third one's launches leave
     __shared__ uint32_t lh[SORT_BINS];
     const int tid = threadIdx.x;
     const int32_t tile = blockIdx.x;
@@ -149,15 +164,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint2* __restr
     __syncthreads();
     const int bpp = od->bpp;
     const uint32_t shift = (uint32_t)(pass * bpp), mask = (1u << bpp) - 1u;
-    const int64_t base = (int64_t)tile * SORT_TILE;
+    const int64_t base = (int64_t)tile * TILE;
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * SORT_THREADS + tid;
         if (idx < n) atomicAdd(&lh[(pairs[idx].x >> shift) & mask], 1u);
     }
     __syncthreads();
-    H[(size_t)tid * tiles + tile] = lh[tid];
-    H[(size_t)(tid + SORT_THREADS) * tiles + tile] = lh[tid + SORT_THREADS];
+    H[(size_t)tid * hstride + tile] = lh[tid];
+    H[(size_t)(tid + SORT_THREADS) * hstride + tile] = lh[tid + SORT_THREADS];
+    if (tile == (int32_t)gridDim.x - 1)       // the padding columns of every row (the scan runs in place)
+        for (int32_t pad = (int32_t)gridDim.x; pad < hstride; ++pad) {
+            H[(size_t)tid * hstride + pad] = 0u;
+            H[(size_t)(tid + SORT_THREADS) * hstride + pad] = 0u;
+        }
 }
 
 // ---- flat exclusive scan of the count matrix, two launches ------------------------------------------------------------
@@ -174,8 +194,10 @@ __device__ __forceinline__ uint32_t nm_block_sum(uint32_t v, uint32_t* wsum)
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t* __restrict__ H, int64_t len,
-                                                              uint32_t* __restrict__ partial)
+                                                              uint32_t* __restrict__ partial, int pass,
+                                                              const OrderDev* __restrict__ od)
 {
+    if (pass >= od->passes) return;
     __shared__ uint32_t wsum[SCAN_THREADS / 64];
     const int64_t at = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
@@ -192,8 +214,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t* __
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t* __restrict__ H, int64_t len,
-                                                             const uint32_t* __restrict__ partial)
+                                                             const uint32_t* __restrict__ partial, int pass,
+                                                             const OrderDev* __restrict__ od)
 {
+    if (pass >= od->passes) return;
     __shared__ uint32_t wsum[SCAN_THREADS / 64];
     __shared__ uint32_t wpre[SCAN_THREADS / 64];
     // everything before this block's chunk
@@ -250,39 +274,43 @@ struct SortIO {
     uint32_t* order_out;
 };
 
-template <int PASS>
+template <int PASS, int ITEMS, bool DIRECT>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortIO io, int64_t n, int32_t tiles,
+                                                               int32_t hstride,
                                                                const uint32_t* __restrict__ offsets,
                                                                const OrderDev* __restrict__ od)
 {
-    // 68 KB of LDS: more than a kernel may declare statically (the code object then fails to load), so it is
-    // dynamic and the launch asks for it (SCATTER_LDS_BYTES)
+    constexpr int TILE = SORT_THREADS * ITEMS;
+    constexpr int WAVES = SORT_THREADS / 64;
+    constexpr int CNT_STRIDE = SORT_BINS + 4;
+    constexpr int BUF_BYTES = TILE * 8 > WAVES * CNT_STRIDE * 4 ? TILE * 8 : WAVES * CNT_STRIDE * 4;
+    if (PASS >= od->passes) return;       // a short key is sorted in two passes: the third one's launches leave
+    const bool last = PASS + 1 == od->passes;      // this pass writes the permutation, not pairs
+    // up to 68 KB of LDS: more than a kernel may declare statically (the code object then fails to load), so it
+    // is dynamic and the launch asks for it (scatter_lds_bytes)
     extern __shared__ __attribute__((aligned(16))) unsigned char sort_lds[];
-    uint2* buf = (uint2*)sort_lds;                                  // SORT_TILE pairs
+    uint2* buf = (uint2*)sort_lds;                                  // TILE pairs
     uint32_t* cnt = (uint32_t*)sort_lds;                            // before that: every wave's digit counters,
                                                                     // CNT_STRIDE words each ([SORT_BINS]: the bin
                                                                     // of the slots beyond the end of a partial tile)
-    uint32_t* delta = (uint32_t*)(sort_lds + SORT_TILE * 8);        // global offset of a digit's run minus its
+    uint32_t* delta = (uint32_t*)(sort_lds + BUF_BYTES);            // global offset of a digit's run minus its
                                                                     // first LDS slot
-    uint32_t* wsum = delta + SORT_BINS;       // SORT_THREADS / 64 wave totals
-    constexpr int WAVES = SORT_THREADS / 64;
-    constexpr int CNT_STRIDE = SORT_BINS + 4;
-    static_assert(WAVES * CNT_STRIDE * 4 <= SORT_TILE * 8, "the wave counters live in the pair buffer");
+    uint32_t* wsum = delta + SORT_BINS;       // SORT_THREADS / 64 wave totals, twice
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int32_t tile = (int32_t)nm_xcd_batch(blockIdx.x, gridDim.x);
     const int bpp = od->bpp;
     const uint32_t shift = (uint32_t)(PASS * bpp), mask = (1u << bpp) - 1u;
-    const int64_t base = (int64_t)tile * SORT_TILE;
-    const int32_t count = (int32_t)(n - base < SORT_TILE ? n - base : SORT_TILE);
+    const int64_t base = (int64_t)tile * TILE;
+    const int32_t count = (int32_t)(n - base < TILE ? n - base : TILE);
     for (int t = tid; t < WAVES * CNT_STRIDE; t += SORT_THREADS) cnt[t] = 0u;
-    // a wave owns SORT_ITEMS * 64 consecutive pairs of the tile and takes them 64 at a time, lane = position:
+    // a wave owns ITEMS * 64 consecutive pairs of the tile and takes them 64 at a time, lane = position:
     // the order of a tile's pairs is (wave, round, lane).
     // (everything per item is computed unconditionally - slots beyond the end read the tile's last pair and go
     // to a bin of their own; conditional definitions of these arrays cost the compiler 250 registers and spills)
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
-    const int32_t p0 = w * (SORT_ITEMS * 64) + lane;
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+    const int32_t p0 = w * (ITEMS * 64) + lane;
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int32_t p = p0 + i * 64;
         const int64_t at = base + (p < count ? p : count - 1);
         if (PASS == 0) {
@@ -294,6 +322,31 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortIO io, int64_
             val[i] = kv.y;
         }
     }
+    // global offsets of this tile's runs.  from the scanned matrix: one entry per digit.  DIRECT (few tiles, no
+    // scan launches): the digit's row of raw counts - its total, and the part before this tile; the totals are
+    // scanned over the digits below, together with the block's own counts
+    uint32_t g0 = 0, g1 = 0, rowsum = 0;
+    if (DIRECT) {
+        // (rows are 16-byte aligned and at most SORT_DIRECT_TILES long: a handful of independent wide loads)
+        const uint4* r0 = (const uint4*)(offsets + (size_t)(2 * tid) * hstride);
+        const uint4* r1 = (const uint4*)(offsets + (size_t)(2 * tid + 1) * hstride);
+        uint32_t t0 = 0, t1 = 0;
+#pragma unroll
+        for (int q = 0; q < SORT_DIRECT_TILES / 4; ++q) {
+            if (4 * q >= tiles) break;
+            const uint4 a = r0[q], b = r1[q];
+            const int32_t left = tile - 4 * q;        // entries of this quad that belong to tiles before this one
+            g0 += (left > 0 ? a.x : 0u) + (left > 1 ? a.y : 0u) + (left > 2 ? a.z : 0u) + (left > 3 ? a.w : 0u);
+            g1 += (left > 0 ? b.x : 0u) + (left > 1 ? b.y : 0u) + (left > 2 ? b.z : 0u) + (left > 3 ? b.w : 0u);
+            t0 += a.x + a.y + a.z + a.w;
+            t1 += b.x + b.y + b.z + b.w;
+        }
+        g1 += t0;            // digit 2t + 1 starts behind all of digit 2t
+        rowsum = t0 + t1;
+    } else {
+        g0 = offsets[(size_t)(2 * tid) * hstride + tile];
+        g1 = offsets[(size_t)(2 * tid + 1) * hstride + tile];
+    }
     __syncthreads();
     // rank inside the (wave, digit) group: one LDS atomic per pair on the wave's own counter.  a wave's LDS
     // operations execute in program order, so rounds are ranked in order; inside one instruction the lanes
@@ -302,7 +355,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortIO io, int64_
     // but the compactness of a wave's queries depends on it.
     uint32_t* mine = cnt + w * CNT_STRIDE;
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int32_t p = p0 + i * 64;
         const uint32_t d = p < count ? (key[i] >> shift) & mask : (uint32_t)SORT_BINS;
         rank[i] = atomicAdd(&mine[d], 1u);
@@ -320,18 +373,30 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortIO io, int64_
         c1 += cnt[ww * CNT_STRIDE + 2 * tid + 1];
     }
     const uint32_t s = c0 + c1;
-    uint32_t incl = s;
+    uint32_t incl = s, gincl = rowsum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
+        const uint32_t go = DIRECT ? __shfl_up(gincl, off) : 0u;
+        if (lane >= off) {
+            incl += o;
+            gincl += go;
+        }
     }
-    if (lane == 63) wsum[w] = incl;
-    const uint32_t g0 = offsets[(size_t)(2 * tid) * tiles + tile];
-    const uint32_t g1 = offsets[(size_t)(2 * tid + 1) * tiles + tile];
+    if (lane == 63) {
+        wsum[w] = incl;
+        wsum[WAVES + w] = gincl;
+    }
     __syncthreads();
-    uint32_t excl = incl - s;
-    for (int ww = 0; ww < w; ++ww) excl += wsum[ww];
+    uint32_t excl = incl - s, gbase = gincl - rowsum;
+    for (int ww = 0; ww < w; ++ww) {
+        excl += wsum[ww];
+        gbase += wsum[WAVES + ww];
+    }
+    if (DIRECT) {
+        g0 += gbase;
+        g1 += gbase;
+    }
 #pragma unroll
     for (int ww = 0; ww < WAVES; ++ww) {
         cnt[ww * CNT_STRIDE + 2 * tid] = excl + pre0[ww];
@@ -341,17 +406,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortIO io, int64_
     delta[2 * tid + 1] = g1 - (excl + c0);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) rank[i] += mine[(key[i] >> shift) & mask];     // now the LDS slot
+    for (int i = 0; i < ITEMS; ++i) rank[i] += mine[(key[i] >> shift) & mask];     // now the LDS slot
     __syncthreads();       // the counters have been read: the buffer is free
 #pragma unroll
-    for (int i = 0; i < SORT_ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int32_t p = p0 + i * 64;
         if (p < count) buf[rank[i]] = make_uint2(key[i], val[i]);
     }
     __syncthreads();
-    if (PASS < 2) {
+    if (!last) {
 #pragma unroll
-        for (int i = 0; i < SORT_ITEMS; ++i) {
+        for (int i = 0; i < ITEMS; ++i) {
             const int32_t p = i * SORT_THREADS + tid;
             if (p < count) {
                 const uint2 kv = buf[p];
@@ -365,7 +430,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(SortIO io, int64_
         // gather has no locality, while the gather in sorted order reads neighbours in space, which in a
         // scanner's or tiler's output are mostly neighbours in memory)
 #pragma unroll
-        for (int i = 0; i < SORT_ITEMS; ++i) {
+        for (int i = 0; i < ITEMS; ++i) {
             const int32_t p = i * SORT_THREADS + tid;
             if (p < count) {
                 const uint2 kv = buf[p];
@@ -389,7 +454,12 @@ __global__ __launch_bounds__(256) void k_gather_xyz(const double* __restrict__ x
     out[i * 3 + 2] = z;
 }
 
-constexpr size_t SCATTER_LDS_BYTES = (size_t)SORT_TILE * 8 + SORT_BINS * 4 + 64;
+template <int ITEMS>
+constexpr size_t scatter_lds_bytes()
+{
+    constexpr size_t tile = (size_t)SORT_THREADS * ITEMS * 8, counters = (size_t)(SORT_THREADS / 64) * (SORT_BINS + 4) * 4;
+    return (tile > counters ? tile : counters) + SORT_BINS * 4 + 128;
+}
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
 
@@ -397,7 +467,9 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 
 struct OrderScratch {
     size_t keys, pairs_a, pairs_b, hist, partial, total;
+    int32_t items;           // pairs per thread of a tile (SORT_ITEMS_BIG or SORT_ITEMS_SMALL)
     int32_t tiles;
+    int32_t hstride;         // row stride of the count matrix: tiles rounded up to a multiple of four
     int64_t hist_len;
     int32_t scan_blocks;
 };
@@ -411,8 +483,11 @@ static void order_scratch(int64_t n, OrderScratch* S)
         off += align_up(bytes);
         return at;
     };
-    S->tiles = (int32_t)((n + SORT_TILE - 1) / SORT_TILE);
-    S->hist_len = (int64_t)SORT_BINS * S->tiles;
+    S->items = n <= SORT_SMALL_N ? SORT_ITEMS_SMALL : SORT_ITEMS_BIG;
+    const int64_t tile = (int64_t)SORT_THREADS * S->items;
+    S->tiles = (int32_t)((n + tile - 1) / tile);
+    S->hstride = (S->tiles + 3) & ~3;
+    S->hist_len = (int64_t)SORT_BINS * S->hstride;
     S->scan_blocks = (int32_t)((S->hist_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
     S->keys = take((size_t)n * 4);
     S->pairs_a = take((size_t)n * 8);
@@ -429,6 +504,48 @@ size_t nm_order_scratch_bytes(int64_t n)
     return S.total;
 }
 
+template <int ITEMS, bool DIRECT>
+static int order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const OrderDev* od,
+                       const OrderScratch& S, char* w, uint32_t* order, double* sorted_xyz, hipStream_t s)
+{
+    uint32_t* keys = (uint32_t*)(w + S.keys);
+    uint2* pa = (uint2*)(w + S.pairs_a);
+    uint2* pb = (uint2*)(w + S.pairs_b);
+    uint32_t* H = (uint32_t*)(w + S.hist);
+    uint32_t* partial = (uint32_t*)(w + S.partial);
+    const int tiles = S.tiles;
+    constexpr size_t LDS = scatter_lds_bytes<ITEMS>();
+    // (per call: the attribute belongs to the function on the CURRENT device, and a process may own several)
+    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<0, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<1, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<2, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    auto scan = [&](int pass) {
+        if (DIRECT) return;        // the scatter blocks sum the raw counts themselves
+        k_scan_reduce<<<S.scan_blocks, SCAN_THREADS, 0, s>>>(H, S.hist_len, partial, pass, od);
+        k_scan_apply<<<S.scan_blocks, SCAN_THREADS, 0, s>>>(H, S.hist_len, partial, pass, od);
+    };
+    SortIO io{};
+    io.order_out = order;          // whichever pass is the key's last writes the permutation
+    k_order_keys_hist<ITEMS><<<tiles, SORT_THREADS, 0, s>>>(d_xyz, n, stride, od, keys, H, S.hstride);
+    scan(0);
+    io.keys_in = keys;
+    io.pairs_out = pa;
+    k_sort_scatter<0, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
+    k_sort_hist<ITEMS><<<tiles, SORT_THREADS, 0, s>>>(pa, n, 1, od, H, S.hstride);
+    scan(1);
+    io.pairs_in = pa;
+    io.pairs_out = pb;
+    k_sort_scatter<1, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
+    k_sort_hist<ITEMS><<<tiles, SORT_THREADS, 0, s>>>(pb, n, 2, od, H, S.hstride);
+    scan(2);
+    io.pairs_in = pb;
+    io.pairs_out = nullptr;
+    k_sort_scatter<2, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
+    k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
 int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const OrderDev* d_order_dev,
                    void* scratch, size_t scratch_bytes, uint32_t* order, double* sorted_xyz, hipStream_t s)
 {
@@ -436,40 +553,14 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
     order_scratch(n, &S);
     if (scratch_bytes < S.total) NM_FAIL(ctx, NM_ERR_WORKSPACE, "spatial order: scratch %zu < %zu", scratch_bytes, S.total);
     char* w = (char*)scratch;
-    uint32_t* keys = (uint32_t*)(w + S.keys);
-    uint2* pa = (uint2*)(w + S.pairs_a);
-    uint2* pb = (uint2*)(w + S.pairs_b);
-    uint32_t* H = (uint32_t*)(w + S.hist);
-    uint32_t* partial = (uint32_t*)(w + S.partial);
-    const int tiles = S.tiles;
-    auto scan = [&]() {
-        k_scan_reduce<<<S.scan_blocks, SCAN_THREADS, 0, s>>>(H, S.hist_len, partial);
-        k_scan_apply<<<S.scan_blocks, SCAN_THREADS, 0, s>>>(H, S.hist_len, partial);
-    };
-    // (per call: the attribute belongs to the function on the CURRENT device, and a process may own several)
-    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_BYTES));
-    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_BYTES));
-    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCATTER_LDS_BYTES));
-    SortIO io{};
-    k_order_keys_hist<<<tiles, SORT_THREADS, 0, s>>>(d_xyz, n, stride, d_order_dev, keys, H, tiles);
-    scan();
-    io.keys_in = keys;
-    io.pairs_out = pa;
-    k_sort_scatter<0><<<tiles, SORT_THREADS, SCATTER_LDS_BYTES, s>>>(io, n, tiles, H, d_order_dev);
-    k_sort_hist<<<tiles, SORT_THREADS, 0, s>>>(pa, n, 1, d_order_dev, H, tiles);
-    scan();
-    io.pairs_in = pa;
-    io.pairs_out = pb;
-    k_sort_scatter<1><<<tiles, SORT_THREADS, SCATTER_LDS_BYTES, s>>>(io, n, tiles, H, d_order_dev);
-    k_sort_hist<<<tiles, SORT_THREADS, 0, s>>>(pb, n, 2, d_order_dev, H, tiles);
-    scan();
-    io.pairs_in = pb;
-    io.pairs_out = nullptr;
-    io.order_out = order;
-    k_sort_scatter<2><<<tiles, SORT_THREADS, SCATTER_LDS_BYTES, s>>>(io, n, tiles, H, d_order_dev);
-    k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
-    NM_HIP(ctx, hipGetLastError());
-    return NM_OK;
+    if (S.items == SORT_ITEMS_BIG) {
+        if (S.tiles <= SORT_DIRECT_TILES)
+            return order_build<SORT_ITEMS_BIG, true>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, s);
+        return order_build<SORT_ITEMS_BIG, false>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, s);
+    }
+    if (S.tiles <= SORT_DIRECT_TILES)
+        return order_build<SORT_ITEMS_SMALL, true>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, s);
+    return order_build<SORT_ITEMS_SMALL, false>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, s);
 }
 
 // ---- the order as an entry point of its own (inspection, tests) ------------------------------------------------------
