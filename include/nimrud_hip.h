@@ -314,16 +314,22 @@ int nm_halo_pack_cells(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stri
  * announced row: after the host synchronisation EVERY rank returns that status; nobody waits in an
  * all-gather for a rank that has left.  (nm_halo_plan_from_matrix is that decision as a host function
  * of the gathered matrix - n_ranks rows of n_ranks + 3 int64: rows sent to each rank, send capacity,
- * receive capacity, status - exported so that it can be tested without a communicator.)  the send staging area is whatever d_work holds beyond
+ * receive capacity, status - exported so that it can be tested without a communicator.)
+ * NM_HALO_REUSE_PLAN (or-ed into mode, by EVERY rank or by none): the tiles have not changed since this
+ * context's last full call with the same communicator size, rank, mode, tile size and workspace - boxes, cell
+ * sets and the pair counts stand.  the call then packs and exchanges the rows again (the data moves every
+ * step) but skips the three all-gathers and the host synchronisation: a step on a static cloud enqueues and
+ * returns.  nm_halo_stats counts both kinds of call.  the send staging area is whatever d_work holds beyond
  * nm_halo_workspace_bytes(0, n_ranks).  NM_HALO_INCLUDE_SELF (or-ed into mode) makes a rank its own
  * neighbour as well - it then receives its own tile - which is how a one-rank communicator exercises the
  * whole path.  no reference counterpart: the reference is single-process.                              */
 #define NM_COMM_ID_BYTES 128
-enum { NM_HALO_BOXES = 0, NM_HALO_CELLS = 1, NM_HALO_INCLUDE_SELF = 4 };
+enum { NM_HALO_BOXES = 0, NM_HALO_CELLS = 1, NM_HALO_INCLUDE_SELF = 4, NM_HALO_REUSE_PLAN = 8 };
 int nm_comm_unique_id(void* id_out /* NM_COMM_ID_BYTES, host */);
 int nm_comm_create(nm_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id, void** comm_out);
 int nm_comm_destroy(nm_ctx* ctx, void* comm);
 size_t nm_halo_workspace_bytes(int64_t send_capacity_rows, int32_t n_ranks);
+int nm_halo_stats(nm_ctx* ctx, int64_t* host_syncs, int64_t* exchanges);
 int nm_halo_plan_from_matrix(const int64_t* matrix, int32_t n_ranks, int32_t rank, int64_t* send_off,
                              int64_t* recv_off, int64_t* sent_rows, int64_t* recv_rows, int32_t* culprit);
 int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t rank,

@@ -114,6 +114,7 @@ SIGNATURES = {
     "nm_comm_create": (ctypes.c_int, [c_ptr, c_i32, c_i32, c_ptr, ctypes.POINTER(c_ptr)]),
     "nm_comm_destroy": (ctypes.c_int, [c_ptr, c_ptr]),
     "nm_halo_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "nm_halo_stats": (ctypes.c_int, [c_ptr, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "nm_halo_plan_from_matrix": (ctypes.c_int,
                                  [ctypes.POINTER(c_i64), c_i32, c_i32, ctypes.POINTER(c_i64),
                                   ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),

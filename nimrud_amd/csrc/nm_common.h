@@ -73,6 +73,13 @@ struct nm_ctx {
     // consecutive scales with the same candidate window run in one launch (nm_set_fuse_scales)
     bool fuse_scales = true;
     int64_t profile_launches = 0;   // search-kernel launches since nm_profile_begin
+    // the halo exchange's last plan (nm_halo_exchange): the gathered count matrix of a step, kept on the host
+    // so that a step on UNCHANGED tiles (NM_HALO_REUSE_PLAN) needs no host synchronisation to learn the sizes
+    std::vector<int64_t> halo_matrix;
+    int32_t halo_ranks = 0, halo_rank = -1, halo_mode = -1;
+    int64_t halo_n = -1;
+    const void* halo_work = nullptr;
+    int64_t halo_host_syncs = 0, halo_exchanges = 0;
 };
 
 // classifier on the rows of a finished feature matrix, into F.proba / F.label (nm_api.hip)

@@ -541,7 +541,9 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
     if (!ctx) return NM_ERR_INVALID;
     nm_device_guard _nm_guard(ctx->device);
     const bool include_self = (mode & NM_HALO_INCLUDE_SELF) != 0;
-    mode &= ~NM_HALO_INCLUDE_SELF;
+    const bool reuse = (mode & NM_HALO_REUSE_PLAN) != 0;
+    const int32_t mode_key = mode & ~NM_HALO_REUSE_PLAN;
+    mode &= ~(NM_HALO_INCLUDE_SELF | NM_HALO_REUSE_PLAN);
     if (!nccl_comm || n_ranks < 1 || n_ranks > NM_MAX_BOXES || rank < 0 || rank >= n_ranks || !h_recv_rows ||
         !h_sent_rows || !d_work)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_halo_exchange: bad arguments");
@@ -564,7 +566,7 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
         ctx->error = "nm_halo_exchange: bad arguments";
         local_status = NM_ERR_INVALID;
     }
-    const bool contribute = local_status == NM_OK && n > 0;       // an empty tile is a legitimate input
+    bool contribute = local_status == NM_OK && n > 0;       // an empty tile is a legitimate input
     hipStream_t s = (hipStream_t)stream;
     char* w = (char*)d_work;
     double* local = (double*)(w + H.local);
@@ -581,8 +583,27 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
     const int32_t skip = include_self ? -1 : rank;
     const int row = n_ranks + 3;        // entries every rank announces
 
-    // 1. every tile's box; their extrema are the global extrema (geometry.py:37 needs the GLOBAL minimum)
     int rc = NM_OK;
+    OffsetList send_off, recv_off;
+    std::vector<int64_t>& host = ctx->halo_matrix;
+    auto pair = [&](int from, int to) { return host[(size_t)from * row + to]; };
+    // ---- a step on unchanged tiles: the plan of the last full call stands (every rank passes the flag or none
+    //      does: it is part of the collective's contract).  boxes / cell sets, the global extrema and the pair
+    //      counts are still in the workspace and on the host: pack, exchange - no collective but the
+    //      point-to-point group, no host synchronisation
+    // (a rank that is unwell still takes its part in the planned exchange - there is no all-gather to carry its
+    // status - and returns the status afterwards)
+    const bool planned = reuse && ctx->halo_ranks == n_ranks && ctx->halo_rank == rank &&
+                         ctx->halo_mode == mode_key && ctx->halo_n == n && ctx->halo_work == d_work &&
+                         host.size() == (size_t)n_ranks * row &&
+                         host[(size_t)rank * row + n_ranks] <= send_capacity &&
+                         host[(size_t)rank * row + n_ranks + 1] <= recv_capacity_rows;
+    if (reuse && !planned)
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_halo_exchange: NM_HALO_REUSE_PLAN without a matching plan (same "
+                "communicator size, rank, mode, tile size, workspace and capacities as the last full call)");
+    if (planned) contribute = n > 0 && d_xyz && stride >= 3;
+    if (!planned) {
+    // 1. every tile's box; their extrema are the global extrema (geometry.py:37 needs the GLOBAL minimum)
     if (contribute) {
         rc = nm_bounds_scratch(ctx, d_xyz, n, stride, local, nullptr, s);
         if (rc) return rc;
@@ -592,7 +613,7 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
     NM_NCCL(ctx, ncclAllGather(local, boxes, 6, ncclDouble, comm, s));
     k_halo_boxes<<<1, 64, 0, s>>>(boxes, n_ranks, margin, global, d_global_minmax);
     // 2. who needs which of my points
-    DestSet B{boxes, nullptr, nullptr, 0.0, n_ranks, skip};
+    DestSet B0{boxes, nullptr, nullptr, 0.0, n_ranks, skip};
     if (mode == NM_HALO_CELLS) {
         if (contribute) {
             rc = nm_halo_cellset(ctx, d_xyz, n, stride, global, margin, own_cells, w + H.cellset_work,
@@ -600,20 +621,21 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
             if (rc) return rc;
         }
         NM_NCCL(ctx, ncclAllGather(own_cells, cellsets, NM_CELLSET_WORDS, ncclUint32, comm, s));
-        B = DestSet{nullptr, cellsets, global, margin, n_ranks, skip};
+        B0 = DestSet{nullptr, cellsets, global, margin, n_ranks, skip};
     }
     if (contribute) {
-        rc = halo_count(ctx, d_xyz, n, stride, B, counts, s);
+        rc = halo_count(ctx, d_xyz, n, stride, B0, counts, s);
         if (rc) return rc;
     }
     k_halo_announce<<<1, 64, 0, s>>>(counts, n_ranks, send_capacity, recv_capacity_rows, (int64_t)local_status);
     // 3. everybody learns every pair count, every capacity and every status; the one host synchronisation
     NM_NCCL(ctx, ncclAllGather(counts, matrix, (size_t)row, ncclInt64, comm, s));
-    std::vector<int64_t> host((size_t)n_ranks * row);
+    host.assign((size_t)n_ranks * row, 0);
+    ctx->halo_ranks = 0;            // no plan until this call has one
     NM_HIP(ctx, hipMemcpyAsync(host.data(), matrix, host.size() * 8, hipMemcpyDeviceToHost, s));
     NM_HIP(ctx, hipStreamSynchronize(s));
-    auto pair = [&](int from, int to) { return host[(size_t)from * row + to]; };
-    OffsetList send_off, recv_off;
+    ctx->halo_host_syncs += 1;
+    }   // !planned
     int32_t culprit = -1;
     // the matrix is the same on every rank, so either every rank returns here or none does: nobody is
     // left waiting in the exchange for a rank that has given up
@@ -631,6 +653,15 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
                     verdict);
         return verdict;       // this rank's own failure: ctx->error already says what
     }
+    if (!planned) {
+        ctx->halo_ranks = n_ranks; ctx->halo_rank = rank; ctx->halo_mode = mode_key; ctx->halo_n = n;
+        ctx->halo_work = d_work;
+    } else if (d_global_minmax) {
+        NM_HIP(ctx, hipMemcpyAsync(d_global_minmax, global, 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    DestSet B{boxes, nullptr, nullptr, 0.0, n_ranks, skip};
+    if (mode == NM_HALO_CELLS) B = DestSet{nullptr, cellsets, global, margin, n_ranks, skip};
+    ctx->halo_exchanges += 1;
     // 4. pack and exchange: grouped point-to-point, one send and one receive per neighbour
     if (contribute) {
         k_put_offsets<<<1, 64, 0, s>>>(send_off, n_ranks, offsets);
@@ -646,5 +677,14 @@ extern "C" int nm_halo_exchange(nm_ctx* ctx, void* nccl_comm, int32_t n_ranks, i
             NM_NCCL(ctx, ncclRecv(d_recv + recv_off.v[j] * 3, (size_t)from * 3, ncclDouble, j, comm, s));
     }
     NM_NCCL(ctx, ncclGroupEnd());
+    return planned ? local_status : NM_OK;
+}
+
+// how often nm_halo_exchange has synchronised the host and how often it has exchanged, since the context was made
+extern "C" int nm_halo_stats(nm_ctx* ctx, int64_t* host_syncs, int64_t* exchanges)
+{
+    if (!ctx) return NM_ERR_INVALID;
+    if (host_syncs) *host_syncs = ctx->halo_host_syncs;
+    if (exchanges) *exchanges = ctx->halo_exchanges;
     return NM_OK;
 }

@@ -45,7 +45,7 @@ import torch.distributed as dist
 from nimrud_amd import device as _device
 
 CELLSET_WORDS = 65536           # NM_HALO_CELLSET_WORDS: 2^21 coarse cells, one bit each
-HALO_BOXES, HALO_CELLS, HALO_INCLUDE_SELF = 0, 1, 4
+HALO_BOXES, HALO_CELLS, HALO_INCLUDE_SELF, HALO_REUSE_PLAN = 0, 1, 4, 8
 
 
 def halo_margin(edge_lengths, radii):
@@ -226,6 +226,12 @@ class TilePlan(object):
         self.halo_sent = 0
         self.halo_received = 0
         self.include_self = False       # testing aid for one-rank communicators (NM_HALO_INCLUDE_SELF)
+        # static = True: the caller promises that NO rank's tile changes between steps (every rank sets it or
+        # none).  the RCCL exchange then keeps the plan of its first step - boxes, cell sets, pair counts - and
+        # later steps pack and exchange the halo rows again without the all-gathers and without the host
+        # synchronisation that learns the sizes (NM_HALO_REUSE_PLAN): a step enqueues and returns
+        self.static = False
+        self._planned = False
         # the tile's coordinates live at the front of a (N + slack, 3) buffer; halo rows are received
         # straight behind them, so a step never copies the tile
         self._buffer = None
@@ -265,6 +271,17 @@ def exchange_halo_rccl(plan):
     mode = (HALO_CELLS if plan.halo == "cells" else HALO_BOXES) | \
         (HALO_INCLUDE_SELF if plan.include_self else 0)
     sent, received = ctypes.c_int64(0), ctypes.c_int64(0)
+    if plan.static and plan._planned == (mode, n, plan._work.data_ptr(), plan._buffer.data_ptr()):
+        capacity = plan._buffer.shape[0] - n
+        rt.check(rt.lib.nm_halo_exchange(
+            rt.ctx, plan.comm.handle, plan.world, plan.rank, _device.ptr(cloud), n,
+            _device.row_stride(cloud), float(plan.margin), mode | HALO_REUSE_PLAN,
+            ctypes.c_void_p(plan._buffer.data_ptr() + 24 * n), capacity,
+            ctypes.byref(received), ctypes.byref(sent), _device.ptr(glob),
+            _device.ptr(plan._work), plan._work.numel(), rt.stream()))
+        plan.halo_sent, plan.halo_received = int(sent.value), int(received.value)
+        return glob, int(received.value)
+    plan._planned = False
     for _ in range(8):
         nbytes = rt.lib.nm_halo_workspace_bytes(int(plan._send_rows), plan.world)
         if plan._work is None or plan._work.numel() < nbytes:
@@ -279,6 +296,7 @@ def exchange_halo_rccl(plan):
         if rc != _ffi.NM_ERR_WORKSPACE:
             rt.check(rc)
             plan.halo_sent, plan.halo_received = int(sent.value), int(received.value)
+            plan._planned = (mode, n, plan._work.data_ptr(), plan._buffer.data_ptr())
             return glob, int(received.value)
         # some rank (maybe this one) is short of room: every rank is here; grow what this one lacks
         if sent.value > plan._send_rows:

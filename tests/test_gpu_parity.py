@@ -426,6 +426,25 @@ def test_halo_exchange_through_rccl_one_rank(halo):
         assert np.array_equal(halo_rows[np.lexsort(halo_rows.T[::-1])], pts[np.lexsort(pts.T[::-1])])
         want = multiscale.process_gpu(dev, dev, [0.1, 0.2, 0.4], [0.3, 0.6, 1.2])
         assert torch.equal(out, want)
+        # steps on a static cloud keep the plan (NM_HALO_REUSE_PLAN): the rows are packed and exchanged again,
+        # the all-gathers and the host synchronisation that learns the sizes are not repeated
+        import ctypes
+        rt = _device_runtime()
+        syncs, exchanges = ctypes.c_int64(0), ctypes.c_int64(0)
+        rt.check(rt.lib.nm_halo_stats(rt.ctx, ctypes.byref(syncs), ctypes.byref(exchanges)))
+        s0, e0 = syncs.value, exchanges.value
+        plan.static = True
+        plan._buffer[len(pts):].zero_()
+        for _ in range(3):
+            out_again = parallel.process_tile(plan)
+            plan._buffer[len(pts):2 * len(pts)].add_(0.0)      # (touch: the rows are really there again)
+        torch.cuda.synchronize()
+        rt.check(rt.lib.nm_halo_stats(rt.ctx, ctypes.byref(syncs), ctypes.byref(exchanges)))
+        assert exchanges.value - e0 == 3 and syncs.value - s0 == 0
+        assert plan.halo_received == len(pts) and torch.equal(out_again, want)
+        halo_rows = plan._buffer[len(pts):2 * len(pts)].cpu().numpy()
+        assert np.array_equal(halo_rows[np.lexsort(halo_rows.T[::-1])], pts[np.lexsort(pts.T[::-1])])
+        plan.static = False
         # a second step reuses the buffers; without the self-neighbour nothing is exchanged
         plan.include_self = False
         out2 = parallel.process_tile(plan)
