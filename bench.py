@@ -588,6 +588,7 @@ def main():
                 "index_build": ms[1] / args.steps,
                 "search_feature_kernel": ms[2] / args.steps,
             },
+            "workspace_bytes_per_point": (rt._work.numel() / float(n_local_search)) if rt._work is not None else None,
             "voxels_per_scale": voxels,
             "extra_search_passes_per_scale": extra_passes,
         }

@@ -185,6 +185,10 @@ int nm_set_fuse_scales(nm_ctx* ctx, int enabled);
  * as NM_ERR_LATTICE through nm_check (see there).  the workspace depends on the point counts only.
  * bit-identical to nm_multiscale_features with the lattices the host would have built.                 */
 size_t nm_ladder_workspace_bytes(int64_t n_query, int64_t n_search, int32_t n_scales);
+/* the same when the edge lengths are known: scales of EQUAL edge length have one lattice and share one occupancy
+ * index (the reference's ladders are one voxel edge with several radii, nimrud/utils/point_clouds.py:29-35), so
+ * they need its memory once.  never more than nm_ladder_workspace_bytes.                                   */
+size_t nm_ladder_workspace_bytes_for(int64_t n_query, int64_t n_search, const double* edges, int32_t n_scales);
 int nm_ladder_features(nm_ctx* ctx,
                        const double* d_query, int64_t n_query, int64_t query_stride,
                        const double* d_search, int64_t n_search, int64_t search_stride,

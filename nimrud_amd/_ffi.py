@@ -82,6 +82,7 @@ SIGNATURES = {
                                 c_ptr]),
     "nm_set_fuse_scales": (ctypes.c_int, [c_ptr, ctypes.c_int]),
     "nm_ladder_workspace_bytes": (c_size, [c_i64, c_i64, c_i32]),
+    "nm_ladder_workspace_bytes_for": (c_size, [c_i64, c_i64, ctypes.POINTER(c_f64), c_i32]),
     "nm_ladder_features": (ctypes.c_int,
                            [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i64, ctypes.POINTER(c_f64),
                             ctypes.POINTER(c_f64), c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_size,

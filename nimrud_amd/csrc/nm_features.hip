@@ -1994,7 +1994,12 @@ struct LadderLayout {
     size_t total;
 };
 
-static void ladder_layout(int64_t nq, int64_t ns, int n_scales, bool shared, bool knn, LadderLayout* S)
+// edges: the scales' edge lengths, or null.  with them, a scale that has the edge length of an earlier one gets
+// no index of its own (it borrows that scale's: ScaleDev::shared) - a ladder of one voxel edge and three radii
+// needs a third of the index memory.  without them every scale is given room (the upper bound
+// nm_ladder_workspace_bytes reports; any layout made with edges fits inside it).
+static void ladder_layout(int64_t nq, int64_t ns, int n_scales, bool shared, bool knn, LadderLayout* S,
+                          const double* edges = nullptr)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -2022,8 +2027,17 @@ static void ladder_layout(int64_t nq, int64_t ns, int n_scales, bool shared, boo
     S->leaf_capacity = (uint32_t)cap;
     S->hash_capacity = (uint32_t)hcap;
     for (int i = 0; i < n_scales && i < NM_MAX_LADDER; ++i) {
-        S->hash[i] = take((size_t)hcap * sizeof(HashEntry));
-        S->leaf[i] = take((size_t)cap * NM_LEAF_WORDS * 4);
+        int owner = i;
+        if (edges)
+            for (int j = i - 1; j >= 0; --j)
+                if (edges[j] == edges[i]) owner = j;
+        if (owner != i) {
+            S->hash[i] = S->hash[owner];
+            S->leaf[i] = S->leaf[owner];
+        } else {
+            S->hash[i] = take((size_t)hcap * sizeof(HashEntry));
+            S->leaf[i] = take((size_t)cap * NM_LEAF_WORDS * 4);
+        }
         S->counters[i] = take(256);
     }
     if (knn) knn_layout(ns > nq ? ns : nq, n_scales, &off, &S->knn);
@@ -2037,6 +2051,16 @@ extern "C" size_t nm_ladder_workspace_bytes(int64_t n_query, int64_t n_search, i
     LadderLayout S;
     // sized for separate clouds and the kNN fallback so one workspace serves every mode
     ladder_layout(n_query > 0 ? n_query : 1, n_search, n_scales, false, true, &S);
+    return S.total;
+}
+
+// the same with the edge lengths known: scales of equal edge share one index
+extern "C" size_t nm_ladder_workspace_bytes_for(int64_t n_query, int64_t n_search, const double* edges,
+                                                int32_t n_scales)
+{
+    if (!edges || n_scales < 1 || n_scales > NM_MAX_LADDER || n_query < 0 || n_search < 1) return 0;
+    LadderLayout S;
+    ladder_layout(n_query > 0 ? n_query : 1, n_search, n_scales, false, true, &S, edges);
     return S.total;
 }
 
@@ -2208,6 +2232,8 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
     const bool shared = (d_query == d_search && n_query <= n_search && n_query > 0 &&
                          query_stride == search_stride);
     LadderLayout S;
+    // (every scale keeps room of its own here: the caller's lattices decide which scales share an index, not
+    // their edge lengths alone - nm_ladder_put)
     ladder_layout(n_query > 0 ? n_query : 1, n_search, n_scales, shared, ctx->knn_k > 0, &S);
     if (work_bytes < S.total)
         NM_FAIL(ctx, NM_ERR_WORKSPACE, "nm_multiscale_features: workspace %zu < required %zu",
@@ -2258,7 +2284,7 @@ extern "C" int nm_ladder_features(nm_ctx* ctx, const double* d_query, int64_t n_
     const bool shared = (d_query == d_search && n_query <= n_search && n_query > 0 &&
                          query_stride == search_stride);
     LadderLayout S;
-    ladder_layout(n_query > 0 ? n_query : 1, n_search, n_scales, shared, ctx->knn_k > 0, &S);
+    ladder_layout(n_query > 0 ? n_query : 1, n_search, n_scales, shared, ctx->knn_k > 0, &S, edges);
     if (work_bytes < S.total)
         NM_FAIL(ctx, NM_ERR_WORKSPACE, "nm_ladder_features: workspace %zu < required %zu", work_bytes,
                 S.total);

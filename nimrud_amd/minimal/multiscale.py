@@ -76,7 +76,7 @@ def _ladder_into(rt, query, search, shared, bounds, edge_lengths, radii, out, in
     edg = (ctypes.c_double * n_scales)(*[float(e) for e in edge_lengths])
     rad = (ctypes.c_double * n_scales)(*[float(r) for r in radii])
     nq, ns = query.shape[0], search.shape[0]
-    nbytes = rt.lib.nm_ladder_workspace_bytes(nq, ns, n_scales)
+    nbytes = rt.lib.nm_ladder_workspace_bytes_for(nq, ns, edg, n_scales)     # equal edges share an index
     if nbytes == 0:
         raise ValueError("bad ladder arguments (at most 32 scales per call)")
     work = rt.workspace(nbytes)

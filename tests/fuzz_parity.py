@@ -14,6 +14,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t0 = time.time()
 worst = 0.0
+worst_note = ""
 for case in range(n_cases):
     kind = rs.randint(0, 6)
     n = int(rs.randint(200, 20000))
@@ -76,8 +77,21 @@ for case in range(n_cases):
               % (case, kind, n, edges, radii, separate, per_scale, knn, factor, str(err)[:200]), flush=True)
         np.savez("gpurun_out/fuzz_fail_%d.npz" % case, pts=pts, q=q, edges=edges, radii=radii)
         continue
-    eig = np.abs(got - want)[:, [c for s in range(n_scales) for c in (4 * s + 2, 4 * s + 3)]]
-    worst = max(worst, float(eig.max()) if eig.size else 0.0)
+    cols = [c for s in range(n_scales) for c in (4 * s + 2, 4 * s + 3)]
+    eig = np.abs(got - want)[:, cols]
+    if eig.size and float(eig.max()) > worst:
+        worst = float(eig.max())
+        row, cc = np.unravel_index(int(eig.argmax()), eig.shape)
+        sc = cols[cc] // 4
+        # where the largest deviation of the sweep sits: the case, the row, its population and both sides'
+        # eigen-features (enough to rebuild the neighborhood: tests/fuzz_parity.py <n> <seed> is deterministic)
+        worst_note = ("case %d kind %d row %d scale %d (e=%.6g r=%.6g knn=%d separate=%s): population %d, "
+                      "gpu (%.17g, %.17g) oracle (%.17g, %.17g)"
+                      % (case, kind, row, sc, edges[sc], radii[sc], knn, separate, int(got[row, 4 * sc]),
+                         got[row, 4 * sc + 2], got[row, 4 * sc + 3], want[row, 4 * sc + 2], want[row, 4 * sc + 3]))
+        np.savez("gpurun_out/fuzz_worst.npz", pts=pts, q=q, edges=edges, radii=radii, row=row, scale=sc,
+                 knn=knn, factor=factor, got=got[row], want=want[row])
     if case % 20 == 0:
         print("case %d ok (kind %d, n %d, scales %d) %.0f s" % (case, kind, n, n_scales, time.time() - t0), flush=True)
 print("done: %d cases, worst eigen-feature |err| %.3g, %.0f s" % (n_cases, worst, time.time() - t0))
+print("worst: " + worst_note)
