@@ -29,6 +29,12 @@ constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anch
 #ifndef NM_CENTRE_TABLE
 #define NM_CENTRE_TABLE 1
 #endif
+#ifndef NM_FUSE_GATHER
+#define NM_FUSE_GATHER 1        // the index builder gathers the coordinates into sorted order itself
+#endif
+#ifndef NM_DIAG_SUMS
+#define NM_DIAG_SUMS 0          // row walk: sum j*k*n from per-(j+k) sums (adds) instead of a multiply-add per row
+#endif
 #ifndef NM_SLAB_MIN_W
 #define NM_SLAB_MIN_W 11        // windows this wide and wider take the slab-fused path of the search kernel
 #endif
@@ -1316,9 +1322,11 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             const int32_t rhome8 = (__mul24(hz - oz, ey) + (hy - oy)) << 3;
             const int32_t step_z8 = (sgn_z < 0 ? -ey : ey) << 3, step_y8 = sgn_y << 3;
             const unsigned char* rows8 = (const unsigned char*)rows;
-            uint32_t aj[W], bk[W], cj[W];
+            uint32_t aj[W], bk[W], cj[NM_DIAG_SUMS ? 2 * W - 1 : W];
 #pragma unroll
-            for (int i = 0; i < W; ++i) aj[i] = bk[i] = cj[i] = 0u;
+            for (int i = 0; i < W; ++i) aj[i] = bk[i] = 0u;
+#pragma unroll
+            for (int i = 0; i < (NM_DIAG_SUMS ? 2 * W - 1 : W); ++i) cj[i] = 0u;
             // the packed masks are loop-invariant; without this the compiler unpacks all W*W fields
             // ahead of the pass loop and keeps them in W*W registers
 #pragma unroll
@@ -1345,7 +1353,9 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                     const uint32_t t = lut[valid[k] >> 2];
                     aj[j] += t;
                     bk[k] += t;
-                    if (W <= 7)       // low 8 bits = sum k*n (< 256 for W <= 7); a 24-bit multiply keeps them
+                    if (NM_DIAG_SUMS)      // per-(j+k) sums: sum (j+k)^2 n = Syy + 2 Syz + Szz gives sum j*k n
+                        cj[j + k] += t;    // with additions only (a multiply-add costs two issue slots more)
+                    else if (W <= 7)  // low 8 bits = sum k*n (< 256 for W <= 7); a 24-bit multiply keeps them
                         cj[j] = nm_mad24(t, (uint32_t)k, cj[j]);
                     else
                         cj[j] += (t & 0xFFu) * (uint32_t)k;
@@ -1358,7 +1368,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             for (int i = 0; i < W; ++i) {
                 uint32_t na = aj[i] & 0xFFu, xa = (aj[i] >> 8) & 0xFFFu, xxa = aj[i] >> 20;
                 uint32_t nb = bk[i] & 0xFFu, xb = (bk[i] >> 8) & 0xFFFu;
-                uint32_t cji = W <= 7 ? (cj[i] & 0xFFu) : cj[i];
+                uint32_t cji = NM_DIAG_SUMS ? 0u : (W <= 7 ? (cj[i] & 0xFFu) : cj[i]);
                 n += na;
                 sx += xa;
                 sxx += xxa;
@@ -1369,6 +1379,12 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                 szz += nb * (i * i);
                 sxz += xb * i;
                 syz += cji * i;
+            }
+            if (NM_DIAG_SUMS) {
+                uint32_t sdd = 0;
+#pragma unroll
+                for (int i = 1; i < 2 * W - 1; ++i) sdd += (cj[i] & 0xFFu) * (uint32_t)(i * i);
+                syz = (sdd - syy - szz) >> 1;
             }
             // the ten integer moments wait in registers; the eigen-solve runs once, after the last
             // pass, for all lanes together (an extra pass costs staging + this row walk only)
@@ -2084,8 +2100,11 @@ static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, c
 {
     const ScaleDev* d_ladder = (const ScaleDev*)(w + S.ladder);
     const OrderDev* d_order = (const OrderDev*)(w + S.order_dev);
+    // (the search cloud's coordinates are gathered into sorted order by the index builder below: no gather
+    // kernel, one read of the sorted copy less.  NM_FUSE_GATHER = 0: a gather kernel behind the sort)
     int rc = nm_order_build(ctx, C.d_search, C.n_search, C.search_stride, d_order, w + S.order_scratch,
-                            S.order_scratch_bytes, (uint32_t*)(w + S.s_order), (double*)(w + S.s_xyz), s);
+                            S.order_scratch_bytes, (uint32_t*)(w + S.s_order),
+                            NM_FUSE_GATHER ? nullptr : (double*)(w + S.s_xyz), s);
     if (rc) return rc;
     const uint32_t* q_order = (const uint32_t*)(w + S.s_order);
     const double* q_xyz = (const double*)(w + S.s_xyz);
@@ -2101,7 +2120,12 @@ static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, c
     // points and walks the scales), one counts them all at the end
     rc = nm_index_clear_all(ctx, d_ladder, C.n_scales, s);
     if (rc) return rc;
-    rc = nm_index_build_ladder(ctx, (const double*)(w + S.s_xyz), C.n_search, d_ladder, 0, C.n_scales, s);
+    if (NM_FUSE_GATHER)
+        rc = nm_index_build_ladder_gather(ctx, C.d_search, C.n_search, C.search_stride,
+                                          (const uint32_t*)(w + S.s_order), (double*)(w + S.s_xyz), d_ladder, 0,
+                                          C.n_scales, s);
+    else
+        rc = nm_index_build_ladder(ctx, (const double*)(w + S.s_xyz), C.n_search, d_ladder, 0, C.n_scales, s);
     if (rc) return rc;
     nm_profile_mark(ctx, s);           // end of the "index" stage
 

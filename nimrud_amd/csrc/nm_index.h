@@ -22,7 +22,8 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
 
 // whole-ladder path: one spatial order for all scales, every scale described by a ScaleDev in device memory.
 // order[i] = original row of sorted slot i (sorted by the compact cell key of the lattice in *d_order_dev,
-// nm_order.hip), sorted_xyz = the coordinates in that order, (n,3) contiguous.  scratch: nm_order_scratch_bytes(n)
+// nm_order.hip), sorted_xyz = the coordinates in that order, (n,3) contiguous - or null: the caller gathers them
+// itself (nm_index_build_ladder_gather).  scratch: nm_order_scratch_bytes(n)
 size_t nm_order_scratch_bytes(int64_t n);
 int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const OrderDev* d_order_dev,
                    void* scratch, size_t scratch_bytes, uint32_t* order, double* sorted_xyz, hipStream_t s);
@@ -54,3 +55,8 @@ int nm_index_count_all(nm_ctx* ctx, const ScaleDev* d_ladder, int n, hipStream_t
 // indexes of scales [first, first + count) from a spatially coherent coordinate stream (no sort)
 int nm_index_build_ladder(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const ScaleDev* d_ladder,
                           int first, int count, hipStream_t s);
+// the same from the cloud in the caller's order plus the permutation of the spatial sort: the builder gathers
+// the coordinates into sorted_xyz itself (nm_order_build was then called with sorted_xyz = nullptr)
+int nm_index_build_ladder_gather(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                                 const uint32_t* order, double* sorted_xyz, const ScaleDev* d_ladder, int first,
+                                 int count, hipStream_t s);

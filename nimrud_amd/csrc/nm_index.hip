@@ -728,10 +728,18 @@ constexpr int FUSED_TABLE = FUSED_CHUNK / 2;
 constexpr int FUSED_TABLE_BITS = FUSED_ITERS == 16 ? 11 : (FUSED_ITERS == 8 ? 10 : 9);
 static_assert(FUSED_ITERS % FUSED_GROUPS == 0 && (1 << FUSED_TABLE_BITS) == FUSED_TABLE, "fused build geometry");
 
-__global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ xyz, int64_t n,
+// GATHER: the coordinates are not in sorted order yet - `xyz` is the cloud as the caller holds it (row stride
+// `stride`), `order` the permutation the spatial sort has just written: the wave gathers its 256 points, writes
+// them to `sorted` (the copy the search kernel reads, (n,3) contiguous) and keeps them in registers for its own
+// work.  one pass over the cloud less than a gather kernel followed by a builder that reads its output
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ xyz_in, int64_t n,
+                                                     int64_t stride, const uint32_t* __restrict__ order,
+                                                     double* __restrict__ sorted,
                                                      const ScaleDev* __restrict__ ladder,
                                                      int32_t n_scales)
 {
+    const double* __restrict__ xyz = GATHER ? sorted : xyz_in;     // what the hash-form pass re-reads
     __shared__ uint32_t stash_slot[FUSED_CHUNK];     // table slot of the point's superblock
     __shared__ uint16_t stash_local[FUSED_CHUNK];    // the cell's 11 bits inside the superblock
     // phase 1 needs the list of created slots, phase 2 the bit table: same memory
@@ -755,7 +763,8 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
     bool any_dense = false;
     for (int32_t sc = 0; sc < n_scales; ++sc)
         any_dense = any_dense || (ladder[sc].valid && !ladder[sc].shared && ladder[sc].I.hash == nullptr);
-    if (any_dense) {
+    static_assert(FUSED_ITERS == FUSED_GROUPS, "a wave reads its points once");
+    if (any_dense || GATHER) {
         for (int it = 0; it < FUSED_ITERS; it += FUSED_GROUPS) {      // (trip count is block-uniform: barriers)
             const int64_t base = wave_lo + (int64_t)it * 64;
             double px[FUSED_GROUPS], py[FUSED_GROUPS], pz[FUSED_GROUPS];
@@ -766,9 +775,21 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
                 valid[g] = i < n;
                 px[g] = py[g] = pz[g] = 0.0;
                 if (valid[g]) {
-                    px[g] = xyz[i * 3 + 0];
-                    py[g] = xyz[i * 3 + 1];
-                    pz[g] = xyz[i * 3 + 2];
+                    const double* p = GATHER ? xyz_in + (int64_t)order[i] * stride : xyz_in + i * 3;
+                    px[g] = p[0];
+                    py[g] = p[1];
+                    pz[g] = p[2];
+                }
+            }
+            if (GATHER) {
+#pragma unroll
+                for (int g = 0; g < FUSED_GROUPS; ++g) {
+                    const int64_t i = base + g * 64 + lane;
+                    if (valid[g]) {
+                        sorted[i * 3 + 0] = px[g];
+                        sorted[i * 3 + 1] = py[g];
+                        sorted[i * 3 + 2] = pz[g];
+                    }
                 }
             }
 #pragma nounroll
@@ -1400,8 +1421,20 @@ int nm_index_count_all(nm_ctx* ctx, const ScaleDev* d_ladder, int n, hipStream_t
 int nm_index_build_ladder(nm_ctx* ctx, const double* sorted_xyz, int64_t n, const ScaleDev* d_ladder,
                           int first, int count, hipStream_t s)
 {
-    k_index_fused<<<(int)((n + FUSED_CHUNK - 1) / FUSED_CHUNK), 256, 0, s>>>(sorted_xyz, n,
-                                                                              d_ladder + first, count);
+    k_index_fused<false><<<(int)((n + FUSED_CHUNK - 1) / FUSED_CHUNK), 256, 0, s>>>(
+        sorted_xyz, n, 3, nullptr, nullptr, d_ladder + first, count);
+    NM_HIP(ctx, hipGetLastError());
+    return NM_OK;
+}
+
+// the same from the cloud as the caller holds it plus the spatial order: gathers the coordinates into
+// `sorted_xyz` on the way (no gather kernel, one read of the sorted copy less)
+int nm_index_build_ladder_gather(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride,
+                                 const uint32_t* order, double* sorted_xyz, const ScaleDev* d_ladder, int first,
+                                 int count, hipStream_t s)
+{
+    k_index_fused<true><<<(int)((n + FUSED_CHUNK - 1) / FUSED_CHUNK), 256, 0, s>>>(
+        d_xyz, n, stride, order, sorted_xyz, d_ladder + first, count);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }

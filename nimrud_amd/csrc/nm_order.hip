@@ -541,7 +541,7 @@ static int order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stri
     io.pairs_in = pb;
     io.pairs_out = nullptr;
     k_sort_scatter<2, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
-    k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
+    if (sorted_xyz) k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
 }
