@@ -515,7 +515,7 @@ def main():
         alg_bytes = float(np.sum([56.0 * nq + 8.0 * m for m in voxels])) / n_launch
         k_ms = ms[2] / max(launches.value, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        kernel_name = "k_scale_features<7, true, true" if (classify and fused) else "k_scale_features<7, true, false"
+        kernel_name = "k_scale_features<7, 3, true" if (classify and fused) else "k_scale_features<7, 3, false"
         traffic, traffic_src = measured_traffic(nq, kernel_name) if world == 1 else (None, None)
         roofline = {
             "bound": "hbm",

@@ -271,7 +271,8 @@ def exchange_halo_rccl(plan):
     mode = (HALO_CELLS if plan.halo == "cells" else HALO_BOXES) | \
         (HALO_INCLUDE_SELF if plan.include_self else 0)
     sent, received = ctypes.c_int64(0), ctypes.c_int64(0)
-    if plan.static and plan._planned == (mode, n, plan._work.data_ptr(), plan._buffer.data_ptr()):
+    if plan.static and plan._planned and plan._work is not None and \
+            plan._planned == (mode, n, plan._work.data_ptr(), plan._buffer.data_ptr()):
         capacity = plan._buffer.shape[0] - n
         rt.check(rt.lib.nm_halo_exchange(
             rt.ctx, plan.comm.handle, plan.world, plan.rank, _device.ptr(cloud), n,
