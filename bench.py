@@ -202,7 +202,7 @@ def cpu_baseline_multicore(points, edges, radii, sample, workers):
         done = sum(pool.map(_cpu_chunk, tasks))
     dt = time.perf_counter() - t0
     return {"value": done * len(edges) / dt, "unit": "point-scales/s", "cores": workers,
-            "kind": "port", "sample": "same %d-point slice, %d query chunks over %d processes, %.1f s"
+            "kind": "port", "sample": "a %d-point Morton-contiguous slice of the same cloud, %d query chunks over %d processes, %.1f s"
                                       % (len(tile), len(tasks), workers, dt)}
 
 
