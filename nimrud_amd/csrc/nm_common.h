@@ -80,6 +80,7 @@ struct nm_ctx {
     int64_t halo_n = -1;
     const void* halo_work = nullptr;
     int64_t halo_host_syncs = 0, halo_exchanges = 0;
+    uint32_t order_attr_set = 0;    // spatial sort: kernel families whose dynamic-LDS attribute is set (nm_order.hip)
 };
 
 // classifier on the rows of a finished feature matrix, into F.proba / F.label (nm_api.hip)

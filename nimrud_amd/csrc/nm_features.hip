@@ -193,7 +193,8 @@ __device__ __forceinline__ double nm_rsqrt_fast(double x)
 }
 
 #ifndef NM_CUBIC_NEWTON_STEPS
-#define NM_CUBIC_NEWTON_STEPS 4   // quadratic from the chord start: error 1.3e-2, 1e-4, 5e-9, < 1e-16 (one to spare)
+#define NM_CUBIC_NEWTON_STEPS 3   // from the quadratic start: error 6.7e-4, 3.8e-7, 1.3e-13, < 1e-21 (the chord start of
+                                  // round 2 - 1.3e-2 - needed four: one v_rcp_f64 and four fp64 instructions more)
 #endif
 __device__ __forceinline__ void nm_eig3_fast(double a00, double a01, double a02, double a11,
                                              double a12, double a22, double& l0, double& l1,
@@ -220,10 +221,11 @@ __device__ __forceinline__ void nm_eig3_fast(double a00, double a01, double a02,
     const bool top = r >= 0.0;
     const double ra = fabs(r);
     // with x = (lambda - q)/p the characteristic cubic is x^3 - 3x - 2r = 0; for r >= 0 its largest root, in
-    // [sqrt 3, 2], is the one well separated from the other two (r < 0: mirror image).  Newton from the
-    // chord between the end points (the root is concave in r: at most 1.3e-2 below it) is quadratic and
-    // well conditioned (f' >= 6 there); the approximate reciprocal only perturbs the step.
-    double x = nm_fma(ra, 2.0 - 1.7320508075688772, 1.7320508075688772);
+    // [sqrt 3, 2], is the one well separated from the other two (r < 0: mirror image).  Newton from a
+    // quadratic fit of the root (within 6.7e-4 of it) is quadratic and well conditioned (f' >= 6 there);
+    // the approximate reciprocal only perturbs the step.
+    // start: least-squares quadratic through the root 2 cos(acos(ra) / 3) on Chebyshev nodes of [0, 1]
+    double x = nm_fma(ra, nm_fma(ra, -0.05343134715, 0.32018433581), 1.73271398205);
 #pragma unroll
     for (int it = 0; it < NM_CUBIC_NEWTON_STEPS; ++it) {
         const double x2 = x * x;

@@ -515,10 +515,15 @@ static int order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stri
     uint32_t* partial = (uint32_t*)(w + S.partial);
     const int tiles = S.tiles;
     constexpr size_t LDS = scatter_lds_bytes<ITEMS>();
-    // (per call: the attribute belongs to the function on the CURRENT device, and a process may own several)
-    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<0, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<1, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<2, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    // (the attribute belongs to the function on the context's device - a process may own several - and is set
+    // once per context and kernel family: three runtime calls per step are host time a 0.1 ms step can see)
+    constexpr uint32_t family = 1u << ((ITEMS == SORT_ITEMS_BIG ? 0 : 2) + (DIRECT ? 1 : 0));
+    if (!(ctx->order_attr_set & family)) {
+        NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<0, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<1, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        NM_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_scatter<2, ITEMS, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        ctx->order_attr_set |= family;
+    }
     auto scan = [&](int pass) {
         if (DIRECT) return;        // the scatter blocks sum the raw counts themselves
         k_scan_reduce<<<S.scan_blocks, SCAN_THREADS, 0, s>>>(H, S.hist_len, partial, pass, od);

@@ -12,8 +12,9 @@ blocks every wave executes once per scale by what they hold:
     phase A prologue   (the table reads and squared differences: >= 15 ds_read_b64 and >= 20 fp64 instructions)
     phase A            (the inclusion tests: >= 100 v_alignbit_b32)
     row walk           (>= 30 ds_read_b64 and >= 30 ds_read_b32)
-    epilogue           (the eigen-solve: the blocks with v_rcp_f64 / v_rsq_f64 and >= 40 fp64 instructions that are
-                        not the deflation branch: the largest one plus the moment conversion block in front of it)
+    epilogue           (the eigen-solve: the largest block with >= 4 v_rcp_f64 / v_rsq_f64 and >= 40 fp64 instructions
+                        that holds no library division - those are the optional covariance / normal outputs -
+                        plus the moment conversion block in front of it)
 the rest of a wave's instructions (cells, boxes, staging loops, branches - executed a data-dependent number of
 times) is the PMC count (profiles/r3_instruction_mix.json, SQ_INSTS_VALU per wave and scale) minus the instructions
 of the identified blocks, priced at the average cost of the remaining blocks' static mix.
@@ -84,6 +85,7 @@ def main():
             cycles += c
             cls[k] += 1
         table.append({"block": name, "valu": len(valu), "classes": cls, "issue_cycles": cycles,
+                      "library_division": sum(o.startswith("v_div_") for o in ops),
                       "ds_read_b64": sum(o == "ds_read_b64" for o in ops),
                       "ds_read_b32": sum(o == "ds_read_b32" for o in ops),
                       "alignbit": sum(o.startswith("v_alignbit") for o in ops),
@@ -96,7 +98,10 @@ def main():
             role[b["block"]] = "row walk"
         elif b["ds_read_b64"] >= 15 and b["classes"]["f64"] >= 20:
             role[b["block"]] = "phase A prologue (centre table)"
-    solve = [b for b in table if b["classes"]["trans"] >= 4 and b["classes"]["f64"] >= 40 and b["block"] not in role]
+    # (the optional covariance / normal outputs have solves of their own, with library divisions and square roots:
+    # v_div_scale / v_div_fmas; the feature epilogue uses the raw v_rcp / v_rsq seeds)
+    solve = [b for b in table if b["classes"]["trans"] >= 4 and b["classes"]["f64"] >= 40 and
+             b["library_division"] == 0 and b["block"] not in role]
     if solve:
         main_solve = max(solve, key=lambda b: b["valu"])
         role[main_solve["block"]] = "epilogue (moments -> features, eigen-solve)"
