@@ -39,6 +39,18 @@ constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anch
 #define NM_SLAB_MIN_W 11        // windows this wide and wider take the slab-fused path of the search kernel
 #endif
 constexpr int NM_BOX_EX = 62;   // x extent of a staged box: 64-bit rows, kept shifted left by two
+#ifndef NM_XREFLECT
+#define NM_XREFLECT 1           // r = 3e: mirror the window in x as well (a bit-reversed copy of the staged rows)
+#endif
+constexpr int NM_BOX_EX_REFL = 60;   // ... and by two at the other end as well where a reversed copy is read
+// a wave that keeps its rows twice: 430 rows, 72 superblock slots (an extent of 61 x 7 rows touches 9 x 2 superblocks
+// in y and z, 54 slots) and the moment table are 7680 bytes = six of gfx950's 1280-byte LDS granules, 20 waves to a
+// CU.  (512 rows, 9472 bytes, allocate 10240: 16 waves, and the kernel was 4 % slower than without the mirror)
+#ifndef NM_ROWS_CAP_REFL
+#define NM_ROWS_CAP_REFL 430
+#endif
+constexpr int NM_SBT_CAP_REFL = 72;
+constexpr int NM_ANCHOR_EYZ_REFL = 20;
 
 // one launch of the search kernel: the scales [s_begin, s_end) of a ladder whose per-scale data (lattice,
 // index, r^2) lives in device memory.  all scales of one launch share the candidate window (W, dmin) and
@@ -334,11 +346,11 @@ __device__ __forceinline__ void nm_features_from_moments(
     out[3] = l1 * inv_tr;
 }
 
-// upper triangle of the ddof=1 covariance (features.py:43) from the integer moments; gy, gz = -1 where
+// upper triangle of the ddof=1 covariance (features.py:43) from the integer moments; gx, gy, gz = -1 where
 // the moments were taken in a frame mirrored on that axis.  cov = e^2 (n S2 - S1 S1^T) / (n (n - 1))
 __device__ __forceinline__ void nm_covariance_from_moments(
     double n, double sx, double sy, double sz, double sxx, double sxy, double sxz, double syy,
-    double syz, double szz, double gy, double gz, double edge, double* __restrict__ c)
+    double syz, double szz, double gx, double gy, double gz, double edge, double* __restrict__ c)
 {
     if (n < 2.0) {
         c[0] = c[1] = c[2] = c[3] = c[4] = c[5] = 0.0;
@@ -346,20 +358,20 @@ __device__ __forceinline__ void nm_covariance_from_moments(
     }
     const double f = edge * edge / (n * (n - 1.0));
     c[0] = (n * sxx - sx * sx) * f;
-    c[1] = (n * sxy - sx * sy) * f * gy;
-    c[2] = (n * sxz - sx * sz) * f * gz;
+    c[1] = (n * sxy - sx * sy) * f * (gx * gy);
+    c[2] = (n * sxz - sx * sz) * f * (gx * gz);
     c[3] = (n * syy - sy * sy) * f;
     c[4] = (n * syz - sy * sz) * f * (gy * gz);
     c[5] = (n * szz - sz * sz) * f;
 }
 
 // unit eigenvector of the smallest eigenvalue of n S2 - S1 S1^T (the plane normal of the neighborhood), in
-// the true frame (gy, gz = -1 where the moments were taken mirrored), last non-zero of (x, y, z) positive.
+// the true frame (gx, gy, gz = -1 where the moments were taken mirrored), last non-zero of (x, y, z) positive.
 // the smallest eigenvalue comes from the robust solver; its eigenvector is the largest cross product of
 // two rows of A - lambda I, on the matrix scaled to unit size.
 __device__ __forceinline__ void nm_normal_from_moments(
     double n, double sx, double sy, double sz, double sxx, double sxy, double sxz, double syy,
-    double syz, double szz, double gy, double gz, double* __restrict__ v)
+    double syz, double szz, double gx, double gy, double gz, double* __restrict__ v)
 {
     v[0] = v[1] = v[2] = 0.0;
     if (n < 3.0) return;
@@ -397,7 +409,7 @@ __device__ __forceinline__ void nm_normal_from_moments(
         nn = vx * vx + vy * vy + vz * vz;
     }
     const double s = 1.0 / sqrt(nn);
-    vx *= s;
+    vx *= s * gx;
     vy *= s * gy;
     vz *= s * gz;
     const bool flip = vz < 0.0 || (vz == 0.0 && (vy < 0.0 || (vy == 0.0 && vx < 0.0)));
@@ -501,8 +513,9 @@ constexpr double nm_far(double d, double ulo, double uhi)
 }
 
 // the kernel mirrors every lane's window in y and z so that the query lies in the upper half of its
-// home cell on those axes (u in [0, 1/2]); x stays two-sided (mirroring x would cost a bit reversal
-// of every occupancy row).  rows are indexed in that mirrored frame.
+// home cell on those axes (u in [0, 1/2]); rows are indexed in that mirrored frame.  in this table x stays
+// two-sided: mirroring x needs the occupancy rows bit-reversed, which only the r = 3e instance pays for (a
+// second, reversed copy of the staged rows; its classes come from nm_mirrored_class below).
 constexpr RowBound nm_row_bound(int W, double rho2, int j, int k)
 {
     const int c = (W - 1) / 2;
@@ -570,7 +583,24 @@ struct ChainTable {
     uint32_t tested[NM_RHO3_W * NM_RHO3_RPJ];
     uint32_t always[NM_RHO3_W * NM_RHO3_RPJ];
 };
-constexpr ChainTable nm_make_chain(const RowBoundTable& B)
+// class of candidate (i, j, k) of a window mirrored on ALL THREE axes (the query in the upper half of its home
+// cell on each): 0 never inside, 1 always inside, 2 must be tested.  same padding as nm_row_bound.
+constexpr int nm_mirrored_class(int W, double rho2, int i, int j, int k)
+{
+    const int c = (W - 1) / 2;
+    const double eta = 1e-4;
+    const double dx = (double)(i - c), dy = (double)(j - c), dz = (double)(k - c);
+    const double far2 = nm_sq(nm_far(dx, -eta, 0.5 + eta)) + nm_sq(nm_far(dy, -eta, 0.5 + eta)) +
+                        nm_sq(nm_far(dz, -eta, 0.5 + eta));
+    const double near2 = nm_sq(nm_near(dx, -eta, 0.5 + eta)) + nm_sq(nm_near(dy, -eta, 0.5 + eta)) +
+                         nm_sq(nm_near(dz, -eta, 0.5 + eta));
+    if (far2 <= rho2 * (1.0 - 1e-9)) return 1;
+    if (near2 <= rho2 * (1.0 + 1e-9)) return 2;
+    return 0;
+}
+
+// xrefl: the window is mirrored in x too (classes per candidate, no longer symmetric about the centre)
+constexpr ChainTable nm_make_chain(const RowBoundTable& B, bool xrefl)
 {
     constexpr int W = NM_RHO3_W, C = (W - 1) / 2, RPR = NM_RHO3_RPR, RPJ = NM_RHO3_RPJ;
     ChainTable t{};
@@ -582,8 +612,10 @@ constexpr ChainTable nm_make_chain(const RowBoundTable& B)
                 for (int i = W - 1; i >= 0; --i) {
                     const int ad = i > C ? i - C : C - i;
                     const int p = 2 + (k % RPR) * W + i;
-                    if (rb.b < 0 || ad > rb.b) continue;
-                    if (ad <= rb.a) {
+                    int cls = (rb.b < 0 || ad > rb.b) ? 0 : (ad <= rb.a ? 1 : 2);
+                    if (xrefl) cls = nm_mirrored_class(W, 9.0, i, j, k);
+                    if (cls == 0) continue;
+                    if (cls == 1) {
                         t.always[j * RPJ + h] |= 1u << p;
                         continue;
                     }
@@ -597,7 +629,15 @@ constexpr ChainTable nm_make_chain(const RowBoundTable& B)
     return t;
 }
 
-constexpr ChainTable NM_CHAIN_RHO3 = nm_make_chain(NM_BOUNDS_RHO3);
+constexpr ChainTable NM_CHAIN_RHO3 = nm_make_chain(NM_BOUNDS_RHO3, NM_XREFLECT != 0);
+constexpr int nm_chain_tests(const ChainTable& t)
+{
+    int n = 0;
+    for (int r = 0; r < NM_RHO3_W * NM_RHO3_RPJ; ++r)
+        for (int b = 0; b < 32; ++b) n += (t.tested[r] >> b) & 1u;
+    return n;
+}
+static_assert(nm_chain_tests(NM_CHAIN_RHO3) == (NM_XREFLECT ? 88 : 115), "tests per query at r = 3e");
 
 // ceil(2^20 / n) for the divisors the staging loops use (n <= ROWS_CAP): (t * v[n]) >> 20 is t / n, exactly,
 // for every operand the loops form (t < ROWS_CAP; the static_assert below goes through all of them)
@@ -712,10 +752,10 @@ __device__ __forceinline__ void nm_lane_generic(const ScaleArgs& A, const Lattic
     o[2] = out[2];
     o[3] = out[3];
     if (A.cov)
-        nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
+        nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, 1.0, L.edge,
                                    A.cov + (int64_t)qi * A.cstride + 6 * s);
     if (A.normal)
-        nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0,
+        nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, 1.0,
                                A.normal + (int64_t)qi * A.nstride + 3 * s);
     if (n < 2.0) atomicAdd(&stats[8], 1u);
     *sparse_out = n < (double)A.sparse_k;
@@ -931,14 +971,26 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     // wide windows (W >= 11: 121 row masks would need 66 registers) test and walk one y-slab at a time INSIDE the
     // pass loop, behind the staging: their centre table cannot share the row buffer
     constexpr bool SLAB = W >= NM_SLAB_MIN_W;
-    constexpr int CTAB_OFS = ROWS_CAP * 8 + SBT_CAP * 4 + (4 << W);
-    constexpr int SEARCH_BYTES = CTAB_OFS + (SLAB ? 3 * 64 * 8 : 0);
+    // r = 3e: the window is mirrored in x too, per lane (88 instead of 115 tests).  the occupancy cannot be
+    // mirrored per lane at a bearable price (a bit reversal per row and lane), so the staged rows are kept twice,
+    // as read and bit-reversed: a mirrored lane walks the reversed copy and everything else is as for y and z
+    constexpr bool XREFL = NM_XREFLECT && RHO3 && !SLAB;
+    constexpr int BOX_EX = XREFL ? NM_BOX_EX_REFL : NM_BOX_EX;
+    constexpr int RCAP = XREFL ? NM_ROWS_CAP_REFL : ROWS_CAP;
+    constexpr int SCAP = XREFL ? NM_SBT_CAP_REFL : SBT_CAP;
+    constexpr int ANCHOR = XREFL ? NM_ANCHOR_EYZ_REFL : ANCHOR_EYZ;
+    static_assert(RCAP <= ROWS_CAP && ANCHOR * ANCHOR <= RCAP && 3 * ((ANCHOR + 6) / 8 + 1) * ((ANCHOR + 6) / 8 + 1) <= SCAP,
+                  "the anchor box must fit");
+    constexpr int CTAB_OFS = RCAP * 8 + SCAP * 4 + (4 << W);
+    constexpr int REV_OFS = CTAB_OFS + (SLAB ? 3 * 64 * 8 : 0);     // (skewing the copy by 8 or 128 bytes against
+                                                                    //  bank conflicts changes nothing, measured)
+    constexpr int SEARCH_BYTES = REV_OFS + (XREFL ? RCAP * 8 : 0);
     constexpr int STAGE_BYTES = FOREST ? NM_FUSED_FOREST_FEATURES * 64 * 4 : 0;   // = SEARCH_BYTES at W = 7
     constexpr int LDS_BYTES = SEARCH_BYTES > STAGE_BYTES ? SEARCH_BYTES : STAGE_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     uint64_t* rows = (uint64_t*)lds_raw;
-    int32_t* sbt = (int32_t*)(lds_raw + ROWS_CAP * 8);
-    uint32_t* lut = (uint32_t*)(lds_raw + ROWS_CAP * 8 + SBT_CAP * 4);
+    int32_t* sbt = (int32_t*)(lds_raw + RCAP * 8);
+    uint32_t* lut = (uint32_t*)(lds_raw + RCAP * 8 + SCAP * 4);
 
     const int lane = threadIdx.x;
     const int32_t dmin = A.dmin;
@@ -1035,6 +1087,11 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     const double uz_home = qz - (tab ? ctab[128 + tz] : nm_centre(hz, L.min_z, L.edge, L.half_edge));
     const int32_t sgn_y = uy_home < 0.0 ? -1 : 1;
     const int32_t sgn_z = uz_home < 0.0 ? -1 : 1;
+    int32_t sgn_x = 1;
+    if constexpr (XREFL) {
+        const double ux_home = qx - (tab ? ctab[tx + C] : nm_centre(hx, L.min_x, L.edge, L.half_edge));
+        sgn_x = ux_home < 0.0 ? -1 : 1;
+    }
 
     // ---- phase A (once per wave and scale): the inside/outside bit of every candidate that needs a test,
     //      as W-bit row masks packed RPR to a register.  independent of the occupancy.
@@ -1044,12 +1101,12 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         // index i of the y and z tables is in the lane's mirrored frame: cell = home + sgn*(i - C)
         double dx2[W], dy2[W], dz2[W];
         if (tab) {
-            const double* cx = ctab + tx;
+            const double* cx = ctab + tx + C;
             const double* cy = ctab + 64 + ty;
             const double* cz = ctab + 128 + tz;
 #pragma unroll
             for (int i = 0; i < W; ++i) {
-                double d = qx - cx[i];
+                double d = qx - (XREFL ? cx[sgn_x * (i - C)] : cx[i - C]);
                 dx2[i] = d * d;
                 d = qy - cy[sgn_y * (i - C)];
                 dy2[i] = d * d;
@@ -1059,7 +1116,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         } else {
 #pragma unroll
             for (int i = 0; i < W; ++i) {
-                double d = qx - nm_centre(hx + dmin + i, L.min_x, L.edge, L.half_edge);
+                double d = qx - nm_centre(XREFL ? hx + sgn_x * (i - C) : hx + dmin + i, L.min_x, L.edge, L.half_edge);
                 dx2[i] = d * d;
                 d = qy - nm_centre(hy + sgn_y * (i - C), L.min_y, L.edge, L.half_edge);
                 dy2[i] = d * d;
@@ -1144,11 +1201,11 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                 ez64 = (int64_t)hiz - loz + W;
         int32_t ox = lox + dmin, oy = loy + dmin, oz = loz + dmin;
         int32_t ey = (int32_t)ey64, ez = (int32_t)ez64;
-        bool fits = ex64 <= NM_BOX_EX && ey64 <= ROWS_CAP && ez64 <= ROWS_CAP && ey64 * ez64 <= ROWS_CAP;
+        bool fits = ex64 <= BOX_EX && ey64 <= RCAP && ez64 <= RCAP && ey64 * ez64 <= RCAP;
         if (fits) {
             int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - (oy >> NM_SBY_BITS) + 1;
             int32_t nsz = ((oz + ez - 1) >> NM_SBZ_BITS) - (oz >> NM_SBZ_BITS) + 1;
-            fits = 3 * nsy * nsz <= SBT_CAP;
+            fits = 3 * nsy * nsz <= SCAP;
         }
         if (!fits) {
             // (readlane, not a shuffle: the box stays in scalar registers and so does everything derived
@@ -1156,18 +1213,18 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             const int anchor = __ffsll((long long)todo) - 1;
             const int32_t ax = __builtin_amdgcn_readlane(hx, anchor), ay = __builtin_amdgcn_readlane(hy, anchor),
                           az = __builtin_amdgcn_readlane(hz, anchor);
-            ox = ax + dmin - (NM_BOX_EX - W) / 2;
-            oy = ay + dmin - (ANCHOR_EYZ - W) / 2;
-            oz = az + dmin - (ANCHOR_EYZ - W) / 2;
-            ey = ANCHOR_EYZ;
-            ez = ANCHOR_EYZ;
+            ox = ax + dmin - (BOX_EX - W) / 2;
+            oy = ay + dmin - (ANCHOR - W) / 2;
+            oz = az + dmin - (ANCHOR - W) / 2;
+            ey = ANCHOR;
+            ez = ANCHOR;
         }
         ox = __builtin_amdgcn_readfirstlane(ox);
         oy = __builtin_amdgcn_readfirstlane(oy);
         oz = __builtin_amdgcn_readfirstlane(oz);
         ey = __builtin_amdgcn_readfirstlane(ey);
         ez = __builtin_amdgcn_readfirstlane(ez);
-        const bool sel = !done && hx + dmin >= ox && hx + dmax < ox + NM_BOX_EX && hy + dmin >= oy &&
+        const bool sel = !done && hx + dmin >= ox && hx + dmax < ox + BOX_EX && hy + dmin >= oy &&
                          hy + dmax < oy + ey && hz + dmin >= oz && hz + dmax < oz + ez;
 
         // ---- stage: leaf numbers of the box's superblocks (integer divisions by wave-uniform small
@@ -1210,6 +1267,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
             uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
             rows[rr] = (uint64_t)lo | ((uint64_t)hi << 32);
+            if constexpr (XREFL)      // bit b of the reversed row is cell ox + 61 - b
+                ((uint64_t*)(lds_raw + REV_OFS))[rr] = (uint64_t)__brev(hi) | ((uint64_t)__brev(lo) << 32);
         }
         lds_fence();
 
@@ -1318,10 +1377,12 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         }
         } else
         if (sel) {
-            const int32_t rx = hx + dmin - ox;
+            // (mirrored lane: window index i is cell hx - dmin - i, bit ox + 61 - hx + dmin + i of the reversed
+            // row; it has to arrive on bit 2 + i like the others.  hx + dmax < ox + 60 keeps the shift >= 0)
+            const int32_t rx = XREFL && sgn_x < 0 ? ox + 59 + dmin - hx : hx + dmin - ox;
             // row of the home cell, and the lane's signed strides through the mirrored window
             // (byte offsets; 24-bit multiplies are full rate, 32-bit ones a quarter)
-            const int32_t rhome8 = (__mul24(hz - oz, ey) + (hy - oy)) << 3;
+            const int32_t rhome8 = ((__mul24(hz - oz, ey) + (hy - oy)) << 3) + (XREFL && sgn_x < 0 ? REV_OFS : 0);
             const int32_t step_z8 = (sgn_z < 0 ? -ey : ey) << 3, step_y8 = sgn_y << 3;
             const unsigned char* rows8 = (const unsigned char*)rows;
             uint32_t aj[W], bk[W], cj[NM_DIAG_SUMS ? 2 * W - 1 : W];
@@ -1403,7 +1464,8 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     if (emit) {
         double out[4];
         // the moments are in the mirrored frame; so must be the query's offset from its home centre
-        const double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
+        double ux = qx - nm_centre(hx, L.min_x, L.edge, L.half_edge);
+        if constexpr (XREFL) ux = fabs(ux);
         const double uy = fabs(uy_home);
         const double uz = fabs(uz_home);
         nm_features_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
@@ -1417,12 +1479,12 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         if (A.cov)
             nm_covariance_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz,
                                        (double)m_sxx, (double)m_sxy, (double)m_sxz, (double)m_syy,
-                                       (double)m_syz, (double)m_szz, (double)sgn_y, (double)sgn_z,
+                                       (double)m_syz, (double)m_szz, (double)sgn_x, (double)sgn_y, (double)sgn_z,
                                        L.edge, nm_row_ptr(A.cov, qi, A.cstride, 6 * s));
         if (A.normal)
             nm_normal_from_moments((double)m_n, (double)m_sx, (double)m_sy, (double)m_sz, (double)m_sxx,
                                    (double)m_sxy, (double)m_sxz, (double)m_syy, (double)m_syz,
-                                   (double)m_szz, (double)sgn_y, (double)sgn_z,
+                                   (double)m_szz, (double)sgn_x, (double)sgn_y, (double)sgn_z,
                                    nm_row_ptr(A.normal, qi, A.nstride, 3 * s));
     }
     const unsigned long long degenerate = __ballot(emit && m_n < 2u);
@@ -1702,10 +1764,10 @@ __global__ __launch_bounds__(64) void k_knn_fallback(KnnArgs K)
     o[2] = out[2];
     o[3] = out[3];
     if (A.cov)
-        nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, L.edge,
+        nm_covariance_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, 1.0, L.edge,
                                    A.cov + (int64_t)qi * A.cstride + 6 * K.scale);
     if (A.normal)
-        nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0,
+        nm_normal_from_moments(n, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, 1.0, 1.0, 1.0,
                                A.normal + (int64_t)qi * A.nstride + 3 * K.scale);
 }
 
