@@ -39,6 +39,10 @@ constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anch
 #define NM_SLAB_MIN_W 11        // windows this wide and wider take the slab-fused path of the search kernel
 #endif
 constexpr int NM_BOX_EX = 62;   // x extent of a staged box: 64-bit rows, kept shifted left by two
+#ifndef NM_KEEP_QUERY
+#define NM_KEEP_QUERY 1         // the query stays in registers across the scale loop: 0 never, 1 not with the forest
+                                // epilogue (97 registers there: a wave of occupancy), 2 always
+#endif
 #ifndef NM_XREFLECT
 #define NM_XREFLECT 1           // r = 3e: mirror the window in x as well (a bit-reversed copy of the staged rows)
 #endif
@@ -1000,20 +1004,30 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     // the moment table comes from constant data (computing it cost every wave ~70 vector instructions)
     for (int m = lane; m < (1 << W); m += 64) lut[m] = NM_LUT<W>.v[m];
 
-    // every scale of this launch in turn: the wave keeps its 64 queries.  nothing per-lane is carried from
-    // one scale to the next in registers - the query is read again (from L1/L2 now) - so that the loop costs
-    // no registers over the one-scale kernel
+    // every scale of this launch in turn: the wave keeps its 64 queries.  nothing else per-lane is carried from
+    // one scale to the next in registers
+    // the wave keeps its 64 queries in registers through the scale loop (six registers: 94 of the 96 that five
+    // waves allow; read again per scale - from HBM, the L2 has long moved on - the kernel was 3-4 % slower)
+    constexpr bool KEEPQ = NM_KEEP_QUERY >= 2 || (NM_KEEP_QUERY == 1 && !FOREST);
+    const int64_t slot = batch * 64 + lane;
+    bool have0 = slot < A.n_slots;
+    uint32_t qi = 0;
+    double qx0 = 0.0, qy0 = 0.0, qz0 = 0.0;
+    if (have0) {
+        qi = A.order[slot];
+        have0 = qi < A.nq;    // prefix mode: the sorted order also holds the non-query search rows
+    }
+    if (KEEPQ && have0) {
+        const double* p = nm_row_ptr(A.query, A.direct ? (uint32_t)slot : qi, A.qstride, 0);
+        qx0 = p[0];
+        qy0 = p[1];
+        qz0 = p[2];
+    }
 #pragma nounroll
     for (int32_t s = A.s_begin; s < (LOOP ? A.s_end : A.s_begin + 1); ++s) {
-    const int64_t slot = batch * 64 + lane;
-    bool have = slot < A.n_slots;
-    uint32_t qi = 0;
-    double qx = 0.0, qy = 0.0, qz = 0.0;
-    if (have) {
-        qi = A.order[slot];
-        have = qi < A.nq;    // prefix mode: the sorted order also holds the non-query search rows
-    }
-    if (have) {
+    bool have = have0;
+    double qx = qx0, qy = qy0, qz = qz0;
+    if (!KEEPQ && have) {
         const double* p = nm_row_ptr(A.query, A.direct ? (uint32_t)slot : qi, A.qstride, 0);
         qx = p[0];
         qy = p[1];
