@@ -175,7 +175,7 @@ struct LatticeDev {
     double min_x, min_y, min_z;
     double edge;
     double half_edge;           // edge * 0.5 (exact)
-    double inv_edge;            // fl(1 / edge): the fast path of nm_cell_fast
+    double inv_edge;            // fl(1 / edge): the fast path of nm_cell_index
     int32_t wx, wy, wz;         // address widths (geometry.py:56)
     int32_t s0, s1;             // address shifts (geometry.py:62)
     int32_t bx, by, bz;         // bits of the superblock coordinate per axis: max(w - local, 0)
@@ -330,21 +330,35 @@ constexpr int NM_DENSE_LOG2 = NM_DENSE_LOG2_VALUE;     // a scale with at most 2
 // compiled with -ffp-contract=off so nothing fuses.
 __device__ __forceinline__ double nm_cell_f(double p, double mn, double e) { return floor((p - mn) / e); }
 
-// the same cell with the division replaced by a multiplication wherever that provably gives the same floor.
+// the same cell with the division replaced by a multiplication wherever that provably gives the same floor,
+// as an int32 clamped to [lo, hi] (|lo|, |hi| <= 2^30).
 // with x = p - mn (the reference's own subtraction), t = x / e, the reference floors fl(t), |fl(t) - t| <= u|t|
 // (u = 2^-53); q = fl(x * fl(1/e)) has |q - t| <= (2u + u^2)|t|.  so q and fl(t) lie within 3.1 u |q| of each
-// other, and their floors can differ only if an integer lies that close to q.  where q is further than
-// 4 u |q| = |q| 2^-51 from every integer the multiplication's floor IS the reference's; otherwise (also for
-// q = 0 and for non-finite q) the reference's division decides.  lattice-aligned clouds take the slow path
-// for every point; clouds in general position about once in 10^6 points.
-__device__ __forceinline__ double nm_cell_fast(double p, double mn, double e, double inv_e)
+// other, and their floors can differ only if an integer lies that close to q.
+//   * "far enough from every integer" is decided on the high word of q's fraction: at least 2^-19 from the nearest
+//     integer covers 3.1 u |q| for every |q| < 2^31; beyond that both floors lie outside [lo, hi] on the same side
+//     and the clamp makes them equal.  otherwise (also for NaN and infinite q, whose fraction is NaN and fails the
+//     test) the reference's division decides.  lattice-aligned clouds take the slow path for every point; clouds
+//     in general position 4 times in 10^6 points and axes.  (rounds 1-2 tested |q - rint(q)| > |q| 2^-51: one
+//     instruction more.)
+//   * v_cvt_i32_f64 saturates: one conversion and one v_med3_i32 replace two fp64 min/max, a canonicalisation and
+//     two integer min/max.  (inline assembly: in C++ the out-of-range cast is undefined.)
+__device__ __forceinline__ int32_t nm_cell_index(double p, double mn, double e, double inv_e, int32_t lo,
+                                                 int32_t hi)
 {
     const double x = p - mn;
     const double q = x * inv_e;
     double c = floor(q);
-    const double d = q - rint(q);
-    if (!(fabs(d) > fabs(q) * 0x1p-51)) c = floor(x / e);
-    return c;
+    const double fr = __builtin_amdgcn_fract(q);
+    const uint32_t fh = (uint32_t)__double2hiint(fr);
+    // 2^-19 <= fr < 1 - 2^-19   (high words 0x3EC00000 and 0x3FEFFFFC, low words zero)
+    if (!(fh - 0x3EC00000u < 0x3FEFFFFCu - 0x3EC00000u)) {
+        c = floor(x / e);
+        if (!(c == c)) c = -1073741824.0;       // NaN: what nm_clamp_cell's fmax/fmin chain made of it
+    }
+    int32_t ci;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(ci) : "v"(c));
+    return min(max(ci, lo), hi);       // (one v_med3_i32 where the compiler can see lo <= hi)
 }
 
 // voxel centre exactly as geometry.py:137: (cell * e + min_corner) + e*0.5, left to right

@@ -1051,9 +1051,9 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     // coordinates too large for the static window bounds: this scale is left to k_scale_features_fallback
     // (keeping the per-lane walk out of this kernel keeps its registers at 80)
     if (!S->prune_ok) continue;
-    const int32_t hx = nm_clamp_cell(nm_cell_fast(qx, L.min_x, L.edge, L.inv_edge));
-    const int32_t hy = nm_clamp_cell(nm_cell_fast(qy, L.min_y, L.edge, L.inv_edge));
-    const int32_t hz = nm_clamp_cell(nm_cell_fast(qz, L.min_z, L.edge, L.inv_edge));
+    const int32_t hx = nm_cell_index(qx, L.min_x, L.edge, L.inv_edge, -1073741824, 1073741823);
+    const int32_t hy = nm_cell_index(qy, L.min_y, L.edge, L.inv_edge, -1073741824, 1073741823);
+    const int32_t hz = nm_cell_index(qz, L.min_z, L.edge, L.inv_edge, -1073741824, 1073741823);
     // a query whose whole candidate window lies outside the lattice has no neighbors
     const bool far = hx + dmax < 0 || hx + dmin >= (1 << L.wx) || hy + dmax < 0 ||
                      hy + dmin >= (1 << L.wy) || hz + dmax < 0 || hz + dmin >= (1 << L.wz);

@@ -679,16 +679,34 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
 
 __device__ __forceinline__ uint64_t nm_point_key(const double* __restrict__ p, const LatticeDev& L)
 {
-    int32_t cx = nm_clamp_cell(nm_cell_fast(p[0], L.min_x, L.edge, L.inv_edge));
-    int32_t cy = nm_clamp_cell(nm_cell_fast(p[1], L.min_y, L.edge, L.inv_edge));
-    int32_t cz = nm_clamp_cell(nm_cell_fast(p[2], L.min_z, L.edge, L.inv_edge));
-    cx = min(max(cx, 0), (int32_t)((1u << L.wx) - 1u));
-    cy = min(max(cy, 0), (int32_t)((1u << L.wy) - 1u));
-    cz = min(max(cz, 0), (int32_t)((1u << L.wz) - 1u));
+    const int32_t cx = nm_cell_index(p[0], L.min_x, L.edge, L.inv_edge, 0, (int32_t)((1u << L.wx) - 1u));
+    const int32_t cy = nm_cell_index(p[1], L.min_y, L.edge, L.inv_edge, 0, (int32_t)((1u << L.wy) - 1u));
+    const int32_t cz = nm_cell_index(p[2], L.min_z, L.edge, L.inv_edge, 0, (int32_t)((1u << L.wz) - 1u));
     return nm_cell_key((uint32_t)cx, (uint32_t)cy, (uint32_t)cz, L);
 }
 
 constexpr uint32_t BITS_EMPTY = 0xFFFFFFFFu;     // free slot of a block's row-word table
+
+// inclusive OR over the lanes [lane - dist, lane] of a wave (dist = distance to the head of the lane's run),
+// in the vector ALU: four row shifts inside the rows of 16 lanes, then row_bcast15 / row_bcast31 carry lane 15 /
+// 47 into the next row and lane 31 into the upper half - for the lanes whose run reaches that far back.
+// (as six __shfl_up it was six round trips through the LDS crossbar, each waited for)
+__device__ __forceinline__ uint32_t nm_run_or(uint32_t b, int dist, int lane)
+{
+#define NM_RUN_STEP(ctrl, rowmask, cond)                                                                   \
+    {                                                                                                      \
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, ctrl, rowmask, 0xF, true);     \
+        b |= (cond) ? o : 0u;                                                                              \
+    }
+    NM_RUN_STEP(0x111, 0xF, dist >= 1)                 // row_shr:1
+    NM_RUN_STEP(0x112, 0xF, dist >= 2)                 // row_shr:2
+    NM_RUN_STEP(0x114, 0xF, dist >= 4)                 // row_shr:4
+    NM_RUN_STEP(0x118, 0xF, dist >= 8)                 // row_shr:8
+    NM_RUN_STEP(0x142, 0xA, dist > (lane & 15))        // row_bcast15 into rows 1 and 3
+    NM_RUN_STEP(0x143, 0xC, dist > (lane & 31))        // row_bcast31 into rows 2 and 3
+#undef NM_RUN_STEP
+    return b;
+}
 
 // ---- the builder: both passes in one kernel -----------------------------------------------------------
 // it is a chain of dependent memory round trips (coordinates -> key -> table probe -> CAS; leaf number
@@ -819,15 +837,13 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
                         word = (uint32_t)(k >> NM_SBX_BITS);      // superblock * 64 + row inside it
                         b = 1u << ((uint32_t)k & 31u);
                     }
-                    const uint32_t prev = __shfl_up(word, 1);
+                    // (lane 0 keeps its own word in `prev`: it is a head anyway)
+                    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)word, (int)word, 0x138, 0xF, 0xF,
+                                                                                 false);      // wave_shr:1
                     const bool row_head = lane == 0 || word != prev;
                     const unsigned long long rowm = __ballot(row_head);
                     const int seg_start = 63 - __clzll((long long)(rowm & below));
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t other = __shfl_up(b, off);
-                        if (lane - off >= seg_start) b |= other;
-                    }
+                    b = nm_run_or(b, lane - seg_start, lane);
                     const bool tail = valid[g] && (lane == 63 || ((rowm >> (lane + 1)) & 1ull));
                     if (tail) {
                         uint32_t ts = (word * 0x9E3779B1u) >> (32 - FUSED_TABLE_BITS);
