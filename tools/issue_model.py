@@ -10,7 +10,7 @@ instance k_scale_features<7, 3, false, true>, split it into basic blocks, price 
 measured cost of its class (column "4 waves per SIMD": one-wave workgroups, like the kernel's), and identify the four
 blocks every wave executes once per scale by what they hold:
     phase A prologue   (the table reads and squared differences: >= 15 ds_read_b64 and >= 20 fp64 instructions)
-    phase A            (the inclusion tests: >= 100 v_alignbit_b32)
+    phase A            (the inclusion tests: >= 60 v_alignbit_b32)
     row walk           (>= 30 ds_read_b64 and >= 30 ds_read_b32)
     epilogue           (the eigen-solve: the largest block with >= 4 v_rcp_f64 / v_rsq_f64 and >= 40 fp64 instructions
                         that holds no library division - those are the optional covariance / normal outputs -
@@ -92,7 +92,7 @@ def main():
                       "vmem": sum(o.startswith(("global_", "buffer_")) for o in ops)})
     role = {}
     for b in table:
-        if b["alignbit"] >= 100:
+        if b["alignbit"] >= 60:
             role[b["block"]] = "phase A (inclusion tests)"
         elif b["ds_read_b64"] >= 30 and b["ds_read_b32"] >= 30:
             role[b["block"]] = "row walk"
