@@ -753,6 +753,17 @@ def test_bounds_pass_matches_numpy():
         rt.check(rt.lib.nm_bounds(rt.ctx, nm_device.ptr(dev), n, 5, nm_device.ptr(out), rt.stream()))
         got = out.cpu().numpy()
         assert np.array_equal(got[:3], pts[:, :3].min(0)) and np.array_equal(got[3:], pts[:, :3].max(0))
+        # a contiguous (n, 3) cloud takes the flat form (16-byte pairs, axes by position): odd and even n, the
+        # extrema planted in the first and last rows and in the odd tail; 8 bytes off alignment: the row form
+        c3 = np.ascontiguousarray(pts[:, :3])
+        c3[0] = c3.min(0) - 1.0
+        c3[-1] = c3.max(0) + 1.0
+        flat = torch.from_numpy(np.concatenate([[0.0], c3.ravel()])).cuda()
+        for ofs in (1, 0):
+            src = flat[ofs:] if ofs else torch.from_numpy(c3).cuda()
+            rt.check(rt.lib.nm_bounds(rt.ctx, nm_device.ptr(src), n, 3, nm_device.ptr(out), rt.stream()))
+            got = out.cpu().numpy()
+            assert np.array_equal(got[:3], c3.min(0)) and np.array_equal(got[3:], c3.max(0)), (n, ofs)
 
 
 def test_device_built_lattices_match_the_hosts():
