@@ -1084,12 +1084,23 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     const bool tab = NM_CENTRE_TABLE && blox <= bhix && (int64_t)bhix - blox + W <= 64 &&
                      (int64_t)bhiy - bloy + W <= 64 && (int64_t)bhiz - bloz + W <= 64;
     double* ctab = SLAB ? (double*)(lds_raw + CTAB_OFS)
-                        : (double*)rows;      // 3 x 64 doubles; the row buffer is not in use yet
+                        : (double*)rows;      // 3 x 64 doubles, twice; the row buffer is not in use yet
     lds_fence();                       // the previous scale's last pass has read the row buffer
     if (tab) {
-        ctab[lane] = nm_centre(blox + dmin + lane, L.min_x, L.edge, L.half_edge);
-        ctab[64 + lane] = nm_centre(bloy + dmin + lane, L.min_y, L.edge, L.half_edge);
-        ctab[128 + lane] = nm_centre(bloz + dmin + lane, L.min_z, L.edge, L.half_edge);
+        const double ccx = nm_centre(blox + dmin + lane, L.min_x, L.edge, L.half_edge);
+        const double ccy = nm_centre(bloy + dmin + lane, L.min_y, L.edge, L.half_edge);
+        const double ccz = nm_centre(bloz + dmin + lane, L.min_z, L.edge, L.half_edge);
+        ctab[lane] = ccx;
+        ctab[64 + lane] = ccy;
+        ctab[128 + lane] = ccz;
+        if constexpr (!SLAB) {
+            // ... and once more back to front (entry m of a reversed table is entry 63 - m): a mirrored lane
+            // then reads its window with the same compile-time offsets as the others, from another base, instead
+            // of forming an address per candidate
+            ctab[192 + 63 - lane] = ccx;
+            ctab[256 + 63 - lane] = ccy;
+            ctab[320 + 63 - lane] = ccz;
+        }
     }
     lds_fence();
     // table positions of this lane's window (lanes that are done read somewhere harmless)
@@ -1115,16 +1126,17 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         // index i of the y and z tables is in the lane's mirrored frame: cell = home + sgn*(i - C)
         double dx2[W], dy2[W], dz2[W];
         if (tab) {
-            const double* cx = ctab + tx + C;
-            const double* cy = ctab + 64 + ty;
-            const double* cz = ctab + 128 + tz;
+            // (ctab[t - k] = reversed[63 - t + k]: window index i is offset i - C from the lane's base in either)
+            const double* cx = XREFL && sgn_x < 0 ? ctab + 192 + 63 - (tx + C) : ctab + tx + C;
+            const double* cy = sgn_y < 0 ? ctab + 256 + 63 - ty : ctab + 64 + ty;
+            const double* cz = sgn_z < 0 ? ctab + 320 + 63 - tz : ctab + 128 + tz;
 #pragma unroll
             for (int i = 0; i < W; ++i) {
-                double d = qx - (XREFL ? cx[sgn_x * (i - C)] : cx[i - C]);
+                double d = qx - cx[i - C];
                 dx2[i] = d * d;
-                d = qy - cy[sgn_y * (i - C)];
+                d = qy - cy[i - C];
                 dy2[i] = d * d;
-                d = qz - cz[sgn_z * (i - C)];
+                d = qz - cz[i - C];
                 dz2[i] = d * d;
             }
         } else {
@@ -1215,6 +1227,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
                 ez64 = (int64_t)hiz - loz + W;
         int32_t ox = lox + dmin, oy = loy + dmin, oz = loz + dmin;
         int32_t ey = (int32_t)ey64, ez = (int32_t)ez64;
+        int32_t ex = ex64 < BOX_EX ? (int32_t)ex64 : BOX_EX;      // cells of the rows anybody will look at
         bool fits = ex64 <= BOX_EX && ey64 <= RCAP && ez64 <= RCAP && ey64 * ez64 <= RCAP;
         if (fits) {
             int32_t nsy = ((oy + ey - 1) >> NM_SBY_BITS) - (oy >> NM_SBY_BITS) + 1;
@@ -1232,12 +1245,14 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             oz = az + dmin - (ANCHOR - W) / 2;
             ey = ANCHOR;
             ez = ANCHOR;
+            ex = BOX_EX;
         }
         ox = __builtin_amdgcn_readfirstlane(ox);
         oy = __builtin_amdgcn_readfirstlane(oy);
         oz = __builtin_amdgcn_readfirstlane(oz);
         ey = __builtin_amdgcn_readfirstlane(ey);
         ez = __builtin_amdgcn_readfirstlane(ez);
+        ex = __builtin_amdgcn_readfirstlane(ex);
         const bool sel = !done && hx + dmin >= ox && hx + dmax < ox + BOX_EX && hy + dmin >= oy &&
                          hy + dmax < oy + ey && hz + dmin >= oz && hz + dmax < oz + ez;
 
@@ -1267,6 +1282,9 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         // ---- stage: 64-bit x-rows of the box, funnel-shifted out of the 32-bit leaf words
         const int32_t nrows = ey * ez;
         const uint32_t sh = (uint32_t)((ox - 2) & 31);
+        // bit b of a row is cell ox - 2 + b and the selected lanes read bits 2 .. ex + 1: where those end inside
+        // the second leaf word - a wave's 64 queries rarely span more than 40 cells - the third is not fetched
+        const bool third = sh + (uint32_t)ex > 62u;
 #pragma nounroll
         for (int32_t rr = lane; rr < nrows; rr += 64) {
             const int32_t rz = (int32_t)(__umul24((uint32_t)rr, inv_ey) >> 20);   // rr / ey (rr < 512)
@@ -1277,7 +1295,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             int32_t l0 = sbt[t0], l1 = sbt[t0 + 1], l2 = sbt[t0 + 2];
             uint32_t w0 = l0 >= 0 ? I.leaf[(size_t)l0 * NM_LEAF_WORDS + wofs] : 0u;
             uint32_t w1 = l1 >= 0 ? I.leaf[(size_t)l1 * NM_LEAF_WORDS + wofs] : 0u;
-            uint32_t w2 = l2 >= 0 ? I.leaf[(size_t)l2 * NM_LEAF_WORDS + wofs] : 0u;
+            uint32_t w2 = third && l2 >= 0 ? I.leaf[(size_t)l2 * NM_LEAF_WORDS + wofs] : 0u;
             uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
             uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
             rows[rr] = (uint64_t)lo | ((uint64_t)hi << 32);
