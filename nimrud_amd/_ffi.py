@@ -42,7 +42,7 @@ class NmForest(ctypes.Structure):
                 ("d_value", c_ptr), ("d_roots", c_ptr), ("n_nodes", c_i32), ("n_trees", c_i32),
                 ("n_classes", c_i32), ("n_features", c_i32), ("d_packed", c_ptr),
                 ("d_leaf_value", c_ptr), ("d_packed_roots", c_ptr), ("n_leaves", c_i32),
-                ("reserved", c_i32), ("d_packed8", c_ptr)]
+                ("leaf_stride", c_i32), ("d_packed8", c_ptr)]
 
 
 _LATP = ctypes.POINTER(NmLattice)

@@ -181,7 +181,8 @@ extern "C" int nm_set_fuse_scales(nm_ctx* ctx, int enabled)
 extern "C" int nm_set_forest_mode(nm_ctx* ctx, int in_search_kernel)
 {
     if (!ctx) return NM_ERR_INVALID;
-    ctx->forest_epilogue = in_search_kernel != 0;
+    ctx->forest_epilogue = in_search_kernel == 1;
+    ctx->forest_mode = in_search_kernel;
     return NM_OK;
 }
 
@@ -204,13 +205,19 @@ extern "C" int nm_set_forest_output(nm_ctx* ctx, const nm_forest* forest, double
                                      "nm_forest_eval", NM_FUSED_FOREST_FEATURES, NM_FUSED_FOREST_CLASSES);
     if ((!d_proba && !d_label) || (d_proba && proba_stride < forest->n_classes))
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_forest_output: bad output arguments");
+    if (forest->leaf_stride && (forest->leaf_stride < forest->n_classes ||
+                                (forest->leaf_stride == 8 && ((uintptr_t)forest->d_leaf_value & 63))))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_set_forest_output: leaf_stride below n_classes, or rows of 8 doubles that "
+                                     "are not 64-byte aligned");
     ForestDev F;
     F.nodes = (const uint2*)forest->d_packed8;
     F.leaf_value = forest->d_leaf_value;
+    F.leaf_stride = forest->leaf_stride ? forest->leaf_stride : forest->n_classes;
     F.roots = forest->d_packed_roots;
     F.n_trees = forest->n_trees;
     F.n_classes = forest->n_classes;
     F.n_features = forest->n_features;
+    F.n_nodes = forest->n_nodes;
     F.proba = d_proba;
     F.pstride = proba_stride;
     F.label = d_label;
@@ -359,10 +366,8 @@ __global__ __launch_bounds__(256) void k_forest_eval_packed(nm_forest F, const d
 #pragma unroll
         for (int g = 0; g < NM_FOREST_TREES; ++g) {
             if (t0 + g >= F.n_trees) break;
-            const double* val = F.d_leaf_value + (int64_t)rec[g].feature * F.n_classes;
-#pragma unroll
-            for (int c = 0; c < NM_MAX_CLASSES; ++c)
-                if (c < F.n_classes) acc[c] += val[c];
+            nm_forest_vote<NM_MAX_CLASSES>(F.d_leaf_value, F.leaf_stride ? F.leaf_stride : F.n_classes, F.n_classes,
+                                           (uint32_t)rec[g].feature, acc);
         }
     }
     int best = 0;
@@ -424,10 +429,7 @@ __global__ __launch_bounds__(256) void k_forest_eval_packed8(ForestDev F, const 
 #pragma unroll
         for (int g = 0; g < NM_FOREST_TREES; ++g) {
             if (t0 + g >= F.n_trees) break;
-            const double* val = F.leaf_value + (int64_t)((rec[g].y >> 13) & 0x3FFFFu) * F.n_classes;
-#pragma unroll
-            for (int c = 0; c < NM_MAX_CLASSES; ++c)
-                if (c < F.n_classes) acc[c] += val[c];
+            nm_forest_vote<NM_MAX_CLASSES>(F.leaf_value, F.leaf_stride, F.n_classes, (rec[g].y >> 13) & 0x3FFFFu, acc);
         }
     }
     int best = 0;
@@ -446,12 +448,215 @@ __global__ __launch_bounds__(256) void k_forest_eval_packed8(ForestDev F, const 
     if (F.label) F.label[i] = best;
 }
 
+// ---- the forest with its trees staged through LDS ------------------------------------------------------------
+// the row-walking evaluators above fetch every node from memory: 64 rows that are neighbours in space part ways a
+// few levels down, a wave-level fetch touches ~30 cache lines, and the walk is bound by the L1's lookup rate
+// (DESIGN.md 3b).  here a 1024-thread workgroup keeps 1024 rows' features in LDS ([wave][feature][lane]: a lane
+// reads its own column, conflict-free) and streams the trees through two LDS buffers, two at a time: a descent
+// step is an LDS read of the node and an LDS read of the feature - one address space, ~100 cycles a step instead
+// of ~700.  a tree's children are adjacent (breadth-first numbering, ForestModel.pack_nodes), so its nodes are
+// one contiguous run of the node array; the staging rebases the child index on the tree's first node.  trees
+// that do not fit a buffer (more than FT_TREE_CAP nodes) are walked from memory as before, pair by pair.
+// votes are added in tree order, as everywhere.
+constexpr int FT_THREADS = 1024;
+constexpr int FT_TREES = 4;              // trees in LDS at a time, walked side by side by every thread
+constexpr int FT_TREE_CAP = 2048;        // nodes per LDS tree buffer (16 KB)
+constexpr int FT_STAGE = FT_TREES * FT_TREE_CAP / FT_THREADS;     // nodes a thread carries from memory to LDS
+constexpr int FT_MAX_FEATURES = 21;      // 16 waves x 21 x 256 B = 84 KB of feature columns
+
+__global__ __launch_bounds__(FT_THREADS) void k_forest_tiles(ForestDev F, const double* __restrict__ feat,
+                                                             int64_t n, int64_t fstride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ft_lds[];
+    uint2* tb = (uint2*)ft_lds;                                   // [FT_TREES][FT_TREE_CAP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nf = F.n_features, nc = F.n_classes;
+    char* xw = (char*)(ft_lds + FT_TREES * FT_TREE_CAP * sizeof(uint2)) + (size_t)w * nf * 256;   // [feature][lane]
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    const uint2* __restrict__ nodes = F.nodes;
+    const int n_stages = (F.n_trees + FT_TREES - 1) / FT_TREES;
+
+    // what a thread carries from memory into the buffers for stage `st`: node k of the flat range
+    // [tree 0's nodes | tree 1's | ...] of that stage, FT_STAGE of them, rebased on their tree's first node
+    auto fetch = [&](int st, uint2* regs, bool& fit) {
+        fit = true;
+#pragma unroll
+        for (int g = 0; g < FT_TREES; ++g) {
+            const int t = st * FT_TREES + g < F.n_trees ? st * FT_TREES + g : F.n_trees - 1;
+            const int32_t r = F.roots[t];
+            const int32_t sz = (t + 1 < F.n_trees ? F.roots[t + 1] : F.n_nodes) - r;
+            fit = fit && sz <= FT_TREE_CAP && sz >= 3;
+#pragma unroll
+            for (int q = 0; q < FT_TREE_CAP / FT_THREADS; ++q) {
+                const int k = tid + q * FT_THREADS;
+                uint2 nd = make_uint2(0x7FC00000u, 1u);
+                if (k < sz && sz <= FT_TREE_CAP && sz >= 3) {
+                    nd = nodes[r + k];
+                    // the LDS form of a node: y = byte offset of the left child inside the buffer << 16 |
+                    // feature << 8; a leaf is a node that steps to itself whatever the row holds - a NaN
+                    // threshold (no value is <= it: the step goes "right") with the leaf's row in its payload,
+                    // and the node before itself as its "left" child - so the walk needs no test per step
+                    if ((int32_t)nd.y >= 0) {
+                        nd.y = ((((nd.y >> 13) - (uint32_t)r) * 8u) << 16) | (nd.y & 0x1F00u);
+                    } else {
+                        nd.x = 0x7FC00000u | ((nd.y >> 13) & 0x3FFFFu);
+                        nd.y = (((uint32_t)k - 1u) * 8u) << 16 | 1u;
+                    }
+                }
+                regs[g * (FT_TREE_CAP / FT_THREADS) + q] = nd;
+            }
+        }
+    };
+
+    for (int64_t chunk = blockIdx.x; chunk * FT_THREADS < n; chunk += gridDim.x) {
+        const int64_t i = chunk * FT_THREADS + tid;
+        const bool have = i < n;
+        bool undefined = false;
+        if (have) {
+            const double* row = feat + i * fstride;
+            for (int f = 0; f < nf; ++f) {
+                const double v = row[f];
+                undefined = undefined || v != v;
+                *(float*)(xw + f * 256 + lane4) = v != v ? 0.0f : (float)v;    // (a NaN would step off a leaf)
+            }
+        } else {
+            for (int f = 0; f < nf; ++f) *(float*)(xw + f * 256 + lane4) = 0.0f;
+        }
+        double acc[NM_FUSED_FOREST_CLASSES];
+#pragma unroll
+        for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c) acc[c] = 0.0;
+        uint2 carry[FT_STAGE];
+        bool fit_next;
+        fetch(0, carry, fit_next);
+        double vote[FT_TREES][NM_FUSED_FOREST_CLASSES];
+        int votes_pending = 0;               // trees of the previous stage whose leaf rows are on their way
+        for (int st = 0; st < n_stages; ++st) {
+            const bool fit = fit_next;
+            __syncthreads();       // the previous stage's walks are over: the buffers are free
+#pragma unroll
+            for (int g = 0; g < FT_TREES; ++g)
+#pragma unroll
+                for (int q = 0; q < FT_TREE_CAP / FT_THREADS; ++q)
+                    tb[g * FT_TREE_CAP + tid + q * FT_THREADS] = carry[g * (FT_TREE_CAP / FT_THREADS) + q];
+            __syncthreads();
+            // the previous stage's votes have had a staging's time to arrive: add them, in tree order
+#pragma unroll
+            for (int g = 0; g < FT_TREES; ++g)
+                if (g < votes_pending)
+#pragma unroll
+                    for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)
+                        if (c < nc) acc[c] += vote[g][c];
+            // the next stage's nodes set out now and travel during this stage's walk
+            if (st + 1 < n_stages) fetch(st + 1, carry, fit_next);
+            uint2 cur[FT_TREES];
+            if (fit) {
+#pragma unroll
+                for (int g = 0; g < FT_TREES; ++g) cur[g] = tb[g * FT_TREE_CAP];
+                // every lane steps every tree, all the time (a leaf steps to itself): the four feature reads of
+                // a level go out together, then the four node reads - two LDS round trips per level, not eight
+                for (;;) {
+                    uint32_t done = cur[0].y;
+#pragma unroll
+                    for (int g = 1; g < FT_TREES; ++g) done &= cur[g].y;
+                    if (__all((done & 1u) != 0u)) break;
+                    float v[FT_TREES];
+#pragma unroll
+                    for (int g = 0; g < FT_TREES; ++g)
+                        v[g] = *(const float*)(xw + ((cur[g].y & 0x1F00u) | lane4));
+#pragma unroll
+                    for (int g = 0; g < FT_TREES; ++g) {
+                        const uint32_t at = (cur[g].y >> 16) + (v[g] <= __uint_as_float(cur[g].x) ? 0u : 8u);
+                        cur[g] = *(const uint2*)((const char*)(tb + g * FT_TREE_CAP) + at);
+                    }
+                }
+                // back to the memory form of a leaf for the votes below
+#pragma unroll
+                for (int g = 0; g < FT_TREES; ++g) cur[g].y = 0x80000000u | ((cur[g].x & 0x3FFFFu) << 13);
+            } else {
+                // a tree of this stage is too large for its buffer: the four are walked from memory
+#pragma unroll
+                for (int g = 0; g < FT_TREES; ++g) {
+                    const int t = st * FT_TREES + g < F.n_trees ? st * FT_TREES + g : F.n_trees - 1;
+                    cur[g] = nodes[F.roots[t]];
+                }
+                for (;;) {
+                    bool go = false;
+#pragma unroll
+                    for (int g = 0; g < FT_TREES; ++g) go = go || (int32_t)cur[g].y >= 0;
+                    if (!__any(go)) break;
+#pragma unroll
+                    for (int g = 0; g < FT_TREES; ++g) {
+                        if ((int32_t)cur[g].y >= 0) {
+                            const float v = *(const float*)(xw + ((cur[g].y & 0x1F00u) | lane4));
+                            cur[g] = nodes[(cur[g].y >> 13) + (v <= __uint_as_float(cur[g].x) ? 0u : 1u)];
+                        }
+                    }
+                }
+            }
+            votes_pending = F.n_trees - st * FT_TREES < FT_TREES ? F.n_trees - st * FT_TREES : FT_TREES;
+#pragma unroll
+            for (int g = 0; g < FT_TREES; ++g) {
+#pragma unroll
+                for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c) vote[g][c] = 0.0;
+                nm_forest_vote<NM_FUSED_FOREST_CLASSES>(F.leaf_value, F.leaf_stride, nc, (cur[g].y >> 13) & 0x3FFFFu,
+                                                        vote[g]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < FT_TREES; ++g)
+            if (g < votes_pending)
+#pragma unroll
+                for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)
+                    if (c < nc) acc[c] += vote[g][c];
+        if (have) {
+            if (undefined) {     // a scale without an addressable lattice left NaN columns: no class
+                if (F.proba)
+                    for (int c = 0; c < nc; ++c) F.proba[i * F.pstride + c] = __builtin_nan("");
+                if (F.label) F.label[i] = -1;
+            } else {
+                int best = 0;
+                double bestv = -1.0;
+#pragma unroll
+                for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c) {
+                    if (c < nc) {
+                        const double pr = acc[c] / (double)F.n_trees;
+                        if (F.proba) F.proba[i * F.pstride + c] = pr;
+                        if (pr > bestv) {   // first maximum wins, like numpy.argmax
+                            bestv = pr;
+                            best = c;
+                        }
+                    }
+                }
+                if (F.label) F.label[i] = best;
+            }
+        }
+    }
+}
+
 int nm_forest_rows(nm_ctx* ctx, const ForestDev& F, const double* d_feat, int64_t feat_stride, int64_t n,
                    int32_t n_features, hipStream_t s)
 {
     if (n <= 0) return NM_OK;
     ForestDev G = F;
     G.n_features = n_features;
+    // rows in no particular order (the stand-alone evaluator, nm_set_forest_mode(2)): trees through LDS - 3.0 ms
+    // for 10 M rows x 32 trees against 3.5 for the row walk from memory.  (behind a ladder the rows come in
+    // spatial order and the walk from memory is the faster one - 2.5 ms, k_forest_ordered - and inside the search
+    // kernel faster still; tools/forest_modes.py measures all of them)
+    if (n_features <= FT_MAX_FEATURES && G.n_classes <= NM_FUSED_FOREST_CLASSES && G.n_nodes > 0 &&
+        n >= 4 * FT_THREADS) {
+        const size_t lds = (size_t)FT_TREES * FT_TREE_CAP * sizeof(uint2) + (size_t)(FT_THREADS / 64) * n_features * 256;
+        if (!ctx->forest_tiles_attr) {
+            NM_HIP(ctx, hipFuncSetAttribute((const void*)k_forest_tiles, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024));
+            ctx->forest_tiles_attr = true;
+        }
+        int64_t blocks = (n + FT_THREADS - 1) / FT_THREADS;
+        if (blocks > ctx->num_cus) blocks = ctx->num_cus;        // one workgroup to a CU: they share nothing
+        k_forest_tiles<<<(int)blocks, FT_THREADS, lds, s>>>(G, d_feat, n, feat_stride);
+        NM_HIP(ctx, hipGetLastError());
+        return NM_OK;
+    }
     k_forest_eval_packed8<<<(int)((n + 255) / 256), 256, 0, s>>>(G, d_feat, n, feat_stride);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
@@ -470,6 +675,11 @@ extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: n_classes must be in [1,%d]", NM_MAX_CLASSES);
     if (forest->n_trees < 1 || forest->n_features < 1 || feat_stride < forest->n_features)
         NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: bad forest shape");
+    if (forest->d_leaf_value && forest->leaf_stride &&
+        (forest->leaf_stride < forest->n_classes ||
+         (forest->leaf_stride == 8 && (forest->n_classes > 8 || ((uintptr_t)forest->d_leaf_value & 63)))))
+        NM_FAIL(ctx, NM_ERR_INVALID, "nm_forest_eval: leaf_stride below n_classes, or rows of 8 doubles that are not "
+                                     "64-byte aligned");
     if (n == 0) return NM_OK;
     const bool packed = forest->d_packed && forest->d_leaf_value && forest->d_packed_roots &&
                         forest->n_features <= NM_FOREST_MAX_FEATURES;
@@ -479,10 +689,12 @@ extern "C" int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double
         ForestDev F;
         F.nodes = (const uint2*)forest->d_packed8;
         F.leaf_value = forest->d_leaf_value;
+        F.leaf_stride = forest->leaf_stride ? forest->leaf_stride : forest->n_classes;
         F.roots = forest->d_packed_roots;
         F.n_trees = forest->n_trees;
         F.n_classes = forest->n_classes;
         F.n_features = forest->n_features;
+        F.n_nodes = forest->n_nodes;
         F.proba = d_proba;
         F.pstride = forest->n_classes;
         F.label = d_label;

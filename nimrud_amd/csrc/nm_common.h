@@ -32,9 +32,11 @@ constexpr int NM_FUSED_FOREST_CLASSES = 8;
 struct ForestDev {
     const uint2* nodes;          // {fp32 threshold rounded down, packed}: bit 31 leaf (row of its class distribution
                                  // << 13); else left child << 13 | feature << 8 (ForestModel.pack_nodes8)
-    const double* leaf_value;    // (n_leaves, n_classes), rows sum to 1
+    const double* leaf_value;    // (n_leaves, leaf_stride), rows sum to 1
+    int32_t leaf_stride;         // doubles per row; 8 and 64-byte aligned rows: fetched with 16-byte loads
     const int32_t* roots;        // root node of each tree
     int32_t n_trees, n_classes, n_features;
+    int32_t n_nodes;             // nodes of all trees (tree t holds nodes roots[t] .. roots[t+1] - 1, breadth-first)
     double* proba;               // (Nq, pstride) or null
     int64_t pstride;
     int32_t* label;              // (Nq,) or null
@@ -68,6 +70,9 @@ struct nm_ctx {
     // classifier behind the last scale of the ladder (nm_set_forest_output)
     bool forest_on = false;
     bool forest_epilogue = true;     // true: inside the last search kernel; false: own launch behind it
+    int forest_mode = 1;             // nm_set_forest_mode: 0 own launch (row walk from memory), 1 epilogue, 2 own
+                                     // launch with the trees staged through LDS (k_forest_tiles)
+    bool forest_tiles_attr = false;  // k_forest_tiles' dynamic-LDS attribute is set
     ForestDev forest{};
     int forest_features = 0;
     // consecutive scales with the same candidate window run in one launch (nm_set_fuse_scales)
@@ -392,6 +397,31 @@ __device__ __forceinline__ uint64_t nm_cell_key(uint32_t cx, uint32_t cy, uint32
     uint64_t sb = nm_sb_key(cx >> NM_SBX_BITS, cy >> NM_SBY_BITS, cz >> NM_SBZ_BITS, L);
     uint32_t local = ((cz & 7u) << 8) | ((cy & 7u) << 5) | (cx & 31u);
     return (sb << NM_LOCAL_BITS) | local;
+}
+
+// acc[c] += the class distribution of leaf `row` (ForestDev::leaf_value).  rows of 8 doubles are 64-byte aligned
+// and zero behind n_classes: 16-byte loads, as many as the classes need, one cache line per lane
+template <int MAXC>
+__device__ __forceinline__ void nm_forest_vote(const double* __restrict__ leaf_value, int32_t stride, int32_t nc,
+                                               uint32_t row, double* acc)
+{
+    static_assert(MAXC >= 8, "the padded form adds up to eight classes");
+    if (stride == 8) {          // (the entry points check: at most 8 classes, rows 64-byte aligned)
+        const double2* v2 = (const double2*)__builtin_assume_aligned(leaf_value + (int64_t)row * 8, 64);
+        const int pairs = (nc + 1) >> 1;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (p < pairs) {
+                const double2 v = v2[p];
+                acc[2 * p] += v.x;
+                acc[2 * p + 1] += v.y;
+            }
+        return;
+    }
+    const double* val = leaf_value + (int64_t)row * stride;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < nc) acc[c] += val[c];
 }
 
 // XCD-aware block -> batch mapping: workgroups are dealt round-robin over the 8 XCDs, so give every

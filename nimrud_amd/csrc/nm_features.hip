@@ -832,9 +832,8 @@ __device__ __forceinline__ void nm_forest_epilogue(const ScaleArgs& A, const uin
 #define NM_FOREST_VOTE(R, OFF)                                                                  \
     _Pragma("unroll") for (int g = 0; g < NM_FOREST_GROUP; ++g) {                               \
         if (t0 + (OFF) + g >= F.n_trees) break;                                                 \
-        const double* val = F.leaf_value + (int64_t)((R[g].y >> 13) & 0x3FFFFu) * F.n_classes;  \
-        _Pragma("unroll") for (int c = 0; c < NM_FUSED_FOREST_CLASSES; ++c)                     \
-            if (c < F.n_classes) acc[c] += val[c];                                              \
+        nm_forest_vote<NM_FUSED_FOREST_CLASSES>(F.leaf_value, F.leaf_stride, F.n_classes,       \
+                                                (R[g].y >> 13) & 0x3FFFFu, acc);                \
     }
     for (int t0 = 0; t0 < F.n_trees; t0 += NM_FOREST_GROUPS * NM_FOREST_GROUP) {
         uint2 ra[NM_FOREST_GROUP], rb[NM_FOREST_GROUP];
@@ -2279,10 +2278,16 @@ static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, c
             i = j;
         }
         if (want_forest && !forest_done) {
-            // the classifier as its own launch behind the last scale, rows taken in the spatial order
-            A.s_begin = 0;
-            A.s_end = C.n_scales;
-            k_forest_ordered<<<(int)((A.n_slots + 63) / 64), 64, 0, s>>>(A, A.F.nodes);
+            if (ctx->forest_mode == 2) {
+                // the classifier as its own launch over the finished matrix, trees staged through LDS
+                rc = nm_forest_rows(ctx, A.F, C.d_feat, C.feat_stride, C.n_query, A.F.n_features, s);
+                if (rc) return rc;
+            } else {
+                // the classifier as its own launch behind the last scale, rows taken in the spatial order
+                A.s_begin = 0;
+                A.s_end = C.n_scales;
+                k_forest_ordered<<<(int)((A.n_slots + 63) / 64), 64, 0, s>>>(A, A.F.nodes);
+            }
         }
     }
     nm_profile_mark(ctx, s);           // end of the "search" stage

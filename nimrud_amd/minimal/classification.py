@@ -50,7 +50,12 @@ class ForestModel(object):
             np.asarray(feature, dtype=np.int32), np.asarray(threshold, dtype=np.float64),
             np.ascontiguousarray(value, dtype=np.float64), np.asarray(roots, dtype=np.int32))
         self.packed = torch.from_numpy(packed.view(np.uint8)).to(dev)
-        self.leaf_value = torch.from_numpy(leaf_value).to(dev)
+        # rows of 8 doubles (64 bytes, zero-padded) for up to 8 classes: a leaf's distribution is one aligned cache
+        # line on the device (nm_forest::leaf_stride); packed rows otherwise
+        self.leaf_stride = 8 if leaf_value.shape[1] <= 8 else leaf_value.shape[1]
+        padded = np.zeros((leaf_value.shape[0], self.leaf_stride), dtype=np.float64)
+        padded[:, :leaf_value.shape[1]] = leaf_value
+        self.leaf_value = torch.from_numpy(padded).to(dev)
         self.packed_roots = torch.from_numpy(packed_roots).to(dev)
         packed8 = self.pack_nodes8(packed, self.n_features)
         self.packed8 = torch.from_numpy(packed8.view(np.uint8)).to(dev) if packed8 is not None else None
@@ -62,7 +67,7 @@ class ForestModel(object):
             n_classes=self.value.shape[1], n_features=self.n_features,
             d_packed=self.packed.data_ptr(), d_leaf_value=self.leaf_value.data_ptr(),
             d_packed_roots=self.packed_roots.data_ptr(), n_leaves=self.leaf_value.shape[0],
-            reserved=0, d_packed8=self.packed8.data_ptr() if self.packed8 is not None else None)
+            leaf_stride=self.leaf_stride, d_packed8=self.packed8.data_ptr() if self.packed8 is not None else None)
 
     @staticmethod
     def pack_nodes(left, right, feature, threshold, value, roots):
