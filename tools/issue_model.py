@@ -9,7 +9,8 @@ method: compile nimrud_amd/csrc/nm_features.hip with the Makefile's flags and --
 instance k_scale_features<7, 3, false, true>, split it into basic blocks, price every vector instruction with the
 measured cost of its class (column "4 waves per SIMD": one-wave workgroups, like the kernel's), and identify the four
 blocks every wave executes once per scale by what they hold:
-    phase A prologue   (the table reads and squared differences: >= 15 ds_read_b64 and >= 20 fp64 instructions)
+    phase A prologue   (the table reads and squared differences: >= 12 ds_read_b64 - pairs count twice - and >= 20 fp64
+                        instructions)
     phase A            (the inclusion tests: >= 60 v_alignbit_b32)
     row walk           (>= 30 ds_read_b64 and >= 30 ds_read_b32)
     epilogue           (the eigen-solve: the largest block with >= 4 v_rcp_f64 / v_rsq_f64 and >= 40 fp64 instructions
@@ -86,7 +87,8 @@ def main():
             cls[k] += 1
         table.append({"block": name, "valu": len(valu), "classes": cls, "issue_cycles": cycles,
                       "library_division": sum(o.startswith("v_div_") for o in ops),
-                      "ds_read_b64": sum(o == "ds_read_b64" for o in ops),
+                      "ds_read_b64": sum(o == "ds_read_b64" for o in ops) +
+                                     2 * sum(o.startswith(("ds_read2_b64", "ds_read2st64_b64")) for o in ops),
                       "ds_read_b32": sum(o == "ds_read_b32" for o in ops),
                       "alignbit": sum(o.startswith("v_alignbit") for o in ops),
                       "vmem": sum(o.startswith(("global_", "buffer_")) for o in ops)})
@@ -96,7 +98,7 @@ def main():
             role[b["block"]] = "phase A (inclusion tests)"
         elif b["ds_read_b64"] >= 30 and b["ds_read_b32"] >= 30:
             role[b["block"]] = "row walk"
-        elif b["ds_read_b64"] >= 15 and b["classes"]["f64"] >= 20:
+        elif b["ds_read_b64"] >= 12 and b["classes"]["f64"] >= 20:
             role[b["block"]] = "phase A prologue (centre table)"
     # (the optional covariance / normal outputs have solves of their own, with library divisions and square roots:
     # v_div_scale / v_div_fmas; the feature epilogue uses the raw v_rcp / v_rsq seeds)
