@@ -21,6 +21,7 @@
 // the staged box are deferred to another pass of the same wave.
 
 #include "nm_common.h"
+#include <type_traits>
 #include "nm_index.h"
 
 constexpr int ROWS_CAP = 512;   // staged (y,z) rows per wave, 8 B each
@@ -955,6 +956,9 @@ __device__ __forceinline__ T* nm_row_ptr(T* base, uint32_t row, int64_t stride, 
 
 // RHO: 0 = the window's static bounds come in the kernel parameter RT; 3, 4, 5 = r is that many edges and the
 // bounds are compile-time constants (RHO = 3, the benchmark's ratio, also has its tests chained at compile time)
+typedef const __attribute__((address_space(1))) uint32_t* NmGlobalU32;
+static_assert(NM_LEAF_WORDS == 64, "leaf words are addressed as (leaf << 6) + word");
+
 template <int W, int RHO, bool FOREST, bool LOOP>
 __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs A, RowBoundTable RT,
                                                        const ScaleDev* __restrict__ scales,
@@ -1284,23 +1288,45 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         // bit b of a row is cell ox - 2 + b and the selected lanes read bits 2 .. ex + 1: where those end inside
         // the second leaf word - a wave's 64 queries rarely span more than 40 cells - the third is not fetched
         const bool third = sh + (uint32_t)ex > 62u;
+        // (the index's pointers come out of the scale array in memory; told that they are global ones the compiler
+        // fetches with global_load.  leaves within 4 GB of the array's start - all but the hash form of clouds beyond
+        // 16 M points - are addressed as base + 32-bit offset: one instruction per address instead of five of 64-bit
+        // arithmetic.  a missing leaf reads leaf 0 and is masked out: no branch around any of the loads)
+        const NmGlobalU32 leaf_g = (NmGlobalU32)I.leaf;
+        const bool near4g = I.leaf_capacity <= (1u << 24);
+        auto stage_rows = [&](auto near_tag) {
+            constexpr bool NEAR = decltype(near_tag)::value;
 #pragma nounroll
-        for (int32_t rr = lane; rr < nrows; rr += 64) {
-            const int32_t rz = (int32_t)(__umul24((uint32_t)rr, inv_ey) >> 20);   // rr / ey (rr < 512)
-            const int32_t y = oy + (rr - __mul24(rz, ey)), z = oz + rz;
-            const int32_t c0 = nm_mad24i((z >> NM_SBZ_BITS) - sbz0, nsy, (y >> NM_SBY_BITS) - sby0);
-            const int32_t t0 = __mul24(c0, 3);
-            uint32_t wofs = (uint32_t)((z & 7) * 8 + (y & 7));
-            int32_t l0 = sbt[t0], l1 = sbt[t0 + 1], l2 = sbt[t0 + 2];
-            uint32_t w0 = l0 >= 0 ? I.leaf[(size_t)l0 * NM_LEAF_WORDS + wofs] : 0u;
-            uint32_t w1 = l1 >= 0 ? I.leaf[(size_t)l1 * NM_LEAF_WORDS + wofs] : 0u;
-            uint32_t w2 = third && l2 >= 0 ? I.leaf[(size_t)l2 * NM_LEAF_WORDS + wofs] : 0u;
-            uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
-            uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-            rows[rr] = (uint64_t)lo | ((uint64_t)hi << 32);
-            if constexpr (XREFL)      // bit b of the reversed row is cell ox + 61 - b
-                ((uint64_t*)(lds_raw + REV_OFS))[rr] = (uint64_t)__brev(hi) | ((uint64_t)__brev(lo) << 32);
-        }
+            for (int32_t rr = lane; rr < nrows; rr += 64) {
+                const int32_t rz = (int32_t)(__umul24((uint32_t)rr, inv_ey) >> 20);   // rr / ey (rr < 512)
+                const int32_t y = oy + (rr - __mul24(rz, ey)), z = oz + rz;
+                const int32_t c0 = nm_mad24i((z >> NM_SBZ_BITS) - sbz0, nsy, (y >> NM_SBY_BITS) - sby0);
+                const int32_t t0 = __mul24(c0, 3);
+                const uint32_t wofs = (uint32_t)((z & 7) * 8 + (y & 7));
+                const int32_t l0 = sbt[t0], l1 = sbt[t0 + 1], l2 = third ? sbt[t0 + 2] : -1;
+                uint32_t w0, w1, w2 = 0u;
+                if constexpr (NEAR) {
+                    const __attribute__((address_space(1))) char* lb = (const __attribute__((address_space(1))) char*)leaf_g;
+                    w0 = *(NmGlobalU32)(lb + (((uint32_t)max(l0, 0) << 8) + wofs * 4u));
+                    w1 = *(NmGlobalU32)(lb + (((uint32_t)max(l1, 0) << 8) + wofs * 4u));
+                    if (third) w2 = *(NmGlobalU32)(lb + (((uint32_t)max(l2, 0) << 8) + wofs * 4u));
+                } else {
+                    w0 = leaf_g[((uint64_t)(uint32_t)max(l0, 0) << 6) + wofs];
+                    w1 = leaf_g[((uint64_t)(uint32_t)max(l1, 0) << 6) + wofs];
+                    if (third) w2 = leaf_g[((uint64_t)(uint32_t)max(l2, 0) << 6) + wofs];
+                }
+                w0 &= ~(uint32_t)(l0 >> 31);
+                w1 &= ~(uint32_t)(l1 >> 31);
+                w2 &= ~(uint32_t)(l2 >> 31);
+                const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+                const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+                rows[rr] = (uint64_t)lo | ((uint64_t)hi << 32);
+                if constexpr (XREFL)      // bit b of the reversed row is cell ox + 61 - b
+                    ((uint64_t*)(lds_raw + REV_OFS))[rr] = (uint64_t)__brev(hi) | ((uint64_t)__brev(lo) << 32);
+            }
+        };
+        if (near4g) stage_rows(std::true_type{});
+        else stage_rows(std::false_type{});
         lds_fence();
 
         // ---- phase B: walk the W*W rows of every selected lane.  branch-free: W row reads, then W
