@@ -44,6 +44,9 @@ constexpr int NM_BOX_EX = 62;   // x extent of a staged box: 64-bit rows, kept s
 #define NM_KEEP_QUERY 1         // the query stays in registers across the scale loop: 0 never, 1 not with the forest
                                 // epilogue (97 registers there: a wave of occupancy), 2 always
 #endif
+#ifndef NM_ADAPTIVE_ANCHOR
+#define NM_ADAPTIVE_ANCHOR 1    // the fallback box around an anchor lane takes its shape from the pending lanes' box
+#endif
 #ifndef NM_XREFLECT
 #define NM_XREFLECT 1           // r = 3e: mirror the window in x as well (a bit-reversed copy of the staged rows)
 #endif
@@ -1243,12 +1246,41 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
             const int anchor = __ffsll((long long)todo) - 1;
             const int32_t ax = __builtin_amdgcn_readlane(hx, anchor), ay = __builtin_amdgcn_readlane(hy, anchor),
                           az = __builtin_amdgcn_readlane(hz, anchor);
+#if NM_ADAPTIVE_ANCHOR
+            // the box around the anchor takes its shape from the pending lanes' own box: the thinner of its (y, z)
+            // extents is kept whole if it is below the default, and the rows that saves widen the other axis -
+            // a scanner's far ground (one or two cell layers in z, lanes metres apart in x and y) or a pole (a few
+            // cells in y, many in z) gets a flat or a tall box instead of 20 x 20 - and on every axis the window is
+            // pushed inside the lanes' range, so that no row of it lies where no lane is.  (all of this is scalar)
+            const bool thin_y = ey64 <= ez64;
+            const int64_t thin64 = thin_y ? ey64 : ez64, wide64 = thin_y ? ez64 : ey64;
+            int32_t thin = thin64 < ANCHOR ? (int32_t)thin64 : ANCHOR;
+            int32_t wide = RCAP / thin;
+            if (wide64 < wide) wide = (int32_t)wide64;
+            if (wide > ROWS_CAP / W) wide = ROWS_CAP / W;
+            if (3 * ((thin + 6) / 8 + 1) * ((wide + 6) / 8 + 1) > SCAP) {
+                thin = ANCHOR;
+                wide = ANCHOR;
+            }
+            ey = thin_y ? thin : wide;
+            ez = thin_y ? wide : thin;
+            ex = BOX_EX;
+            const int32_t cx = ax + dmin - (BOX_EX - W) / 2, cy = ay + dmin - (ey - W) / 2,
+                          cz = az + dmin - (ez - W) / 2;
+            // (window [o, o + e) inside [lo + dmin, hi + dmax] where the range is at least as long)
+            const int64_t hx_end = (int64_t)hix + dmax + 1, hy_end = (int64_t)hiy + dmax + 1,
+                          hz_end = (int64_t)hiz + dmax + 1;
+            ox = ex64 >= BOX_EX ? (int32_t)max((int64_t)lox + dmin, min((int64_t)cx, hx_end - BOX_EX)) : lox + dmin;
+            oy = ey64 >= ey ? (int32_t)max((int64_t)loy + dmin, min((int64_t)cy, hy_end - ey)) : loy + dmin;
+            oz = ez64 >= ez ? (int32_t)max((int64_t)loz + dmin, min((int64_t)cz, hz_end - ez)) : loz + dmin;
+#else
             ox = ax + dmin - (BOX_EX - W) / 2;
             oy = ay + dmin - (ANCHOR - W) / 2;
             oz = az + dmin - (ANCHOR - W) / 2;
             ey = ANCHOR;
             ez = ANCHOR;
             ex = BOX_EX;
+#endif
         }
         ox = __builtin_amdgcn_readfirstlane(ox);
         oy = __builtin_amdgcn_readfirstlane(oy);
