@@ -245,7 +245,16 @@ struct IndexDev {
     uint32_t leaf_capacity;  // leaves the workspace has room for
     uint32_t* counters;      // [0] leaves allocated, [1] occupied cells M (low), [2] overflow flag
     uint32_t* status;        // the context's sticky status words (NM_ST_*)
+    // MAP form (map != nullptr; it lives where the table would): one word per superblock of the lattice, the
+    // leaf number or NM_MAP_EMPTY; hash_mask = number of superblocks - 1.  a lattice with too many superblocks
+    // for a leaf each (dense form) but few enough for a word each - a 50 M-point scan's finest scale: 10 M
+    // superblocks, 0.7 M of them occupied - is found with ONE load and no probing, and cleared in 42 MB instead
+    // of a table sized for as many entries as there are points (0.5 GB)
+    uint32_t* map = nullptr;
 };
+constexpr uint32_t NM_MAP_EMPTY = 0xFFFFFFFFu;      // (what the 0xFF fill leaves)
+constexpr uint32_t NM_MAP_NONE = 0xFFFFFFFEu;       // no room for a leaf (capacity overflow, flagged)
+constexpr uint32_t NM_MAP_PENDING = 0xFFFFFFFDu;    // entered, its leaf not published yet (the builder waits)
 
 // ---- the scale ladder in device memory ------------------------------------------------------------------
 // everything a kernel needs to know about one analysis scale.  the ladder path keeps an array of these in
@@ -448,6 +457,11 @@ __device__ __forceinline__ uint32_t nm_hash64(uint64_t k)
 __device__ __forceinline__ int32_t nm_hash_find(const IndexDev& I, uint64_t key)
 {
     if (!I.hash) return key <= (uint64_t)I.hash_mask ? (int32_t)key : -1;      // dense: leaf = superblock
+    if (I.map) {                                                               // map: a word per superblock
+        if (key > (uint64_t)I.hash_mask) return -1;
+        const uint32_t v = I.map[key];
+        return (int32_t)v >= 0 ? (int32_t)v : -1;
+    }
     uint32_t slot = nm_hash64(key) & I.hash_mask;
     for (;;) {
         const uint4 e = *(const uint4*)&I.hash[slot];          // one 16-byte load: key and value

@@ -25,6 +25,9 @@ __device__ __forceinline__ double nm_order_decode(uint64_t k)
     return __longlong_as_double((long long)b);
 }
 
+#ifndef NM_MAP_FORM
+#define NM_MAP_FORM 1       // the ladder path may index a scale with a word per superblock (IndexDev::map)
+#endif
 #ifndef NM_BOUNDS_BLOCKS
 #define NM_BOUNDS_BLOCKS 1024
 #endif
@@ -877,6 +880,7 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
         const LatticeDev L = ladder[sc].L;
         const IndexDev I = ladder[sc].I;
         const bool dense = I.hash == nullptr;
+        const bool mapf = I.map != nullptr;
         __syncthreads();       // the previous scale's flush has read the scratch
         if (dense) continue;       // done in the first pass
         if (threadIdx.x == 0) won_count = 0u;
@@ -909,8 +913,20 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
     #pragma unroll
             for (int g = 0; g < FUSED_GROUPS; ++g) {
                 // dense index: the "slot" of a superblock is its key, which also is its leaf; nothing to probe
-                slot[g] = dense ? (uint32_t)sb[g] : nm_hash64(sb[g]) & I.hash_mask;
-                peek[g] = (head[g] && !dense) ? I.hash[slot[g]].key : sb[g];
+                slot[g] = dense || mapf ? (uint32_t)sb[g] : nm_hash64(sb[g]) & I.hash_mask;
+                peek[g] = (head[g] && !dense && !mapf) ? I.hash[slot[g]].key : sb[g];
+            }
+            if (mapf) {
+                // map form: the superblock's own word.  whoever turns it from EMPTY to PENDING creates the leaf
+#pragma unroll
+                for (int g = 0; g < FUSED_GROUPS; ++g) {
+                    if (!head[g]) continue;
+                    uint32_t v = __hip_atomic_load(&I.map[slot[g]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v == NM_MAP_EMPTY) {
+                        v = atomicCAS(&I.map[slot[g]], NM_MAP_EMPTY, NM_MAP_PENDING);
+                        if (v == NM_MAP_EMPTY) won_slot[atomicAdd(&won_count, 1u)] = slot[g];
+                    }
+                }
             }
     #pragma unroll
             for (int g = 0; g < FUSED_GROUPS; ++g) {
@@ -975,8 +991,12 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
             __syncthreads();
             for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
                 const uint32_t idx = leaf_base + t;
-                __hip_atomic_store(&I.hash[won_slot[t]].val, idx < I.leaf_capacity ? idx : LEAF_NONE,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (mapf)
+                    __hip_atomic_store(&I.map[won_slot[t]], idx < I.leaf_capacity ? idx : NM_MAP_NONE,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    __hip_atomic_store(&I.hash[won_slot[t]].val, idx < I.leaf_capacity ? idx : LEAF_NONE,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -1004,23 +1024,26 @@ __global__ __launch_bounds__(256) void k_index_fused(const double* __restrict__ 
                 val[g] = LEAF_NONE;
                 if (sb_head[g] && valid[g])
                     val[g] = dense ? sl[g]
-                                   : __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
+                             : mapf ? __hip_atomic_load(&I.map[sl[g]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
             }
     #pragma unroll
             for (int g = 0; g < FUSED_GROUPS; ++g) {
                 if (sb_head[g] && valid[g]) {
                     // not published yet: its creator is still in phase 1.  (a dense index has no creators)
-                    for (int spin = 0; !dense && val[g] == LEAF_PENDING && spin < NM_SPIN_LIMIT; ++spin) {
+                    const uint32_t pending = mapf ? NM_MAP_PENDING : LEAF_PENDING;
+                    for (int spin = 0; !dense && val[g] == pending && spin < NM_SPIN_LIMIT; ++spin) {
                         __builtin_amdgcn_s_sleep(8);
-                        val[g] = __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
+                        val[g] = mapf ? __hip_atomic_load(&I.map[sl[g]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : __hip_atomic_load(&I.hash[sl[g]].val, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
                     }
     #ifdef NM_DIAG_FORCE_TIMEOUT
                     // diagnostic build (tests only): the first block behaves as if its first wait ran out
-                    if (blockIdx.x == 0 && it == 0 && g == 0) val[g] = LEAF_PENDING;
+                    if (blockIdx.x == 0 && it == 0 && g == 0) val[g] = pending;
     #endif
-                    if (val[g] == LEAF_PENDING) {
+                    if (val[g] == pending) {
                         I.counters[3] = 1u;
                         I.status[NM_ST_INDEX_TIMEOUT] = 1u;     // sticky: the next call into the library fails
                         val[g] = LEAF_NONE;
@@ -1110,6 +1133,17 @@ __device__ inline void nm_scale_finish(ScaleDev* S, double radius, uint32_t hash
         S->I.leaf_capacity = 1u << sb_bits;
         leaf_capacity = 0;          // skip the sizing below
     }
+    S->I.map = nullptr;
+#if NM_MAP_FORM
+    // a word per superblock where the table's room holds that (4 B x superblocks <= 16 B x slots): MAP form
+    if (allow_dense && S->I.hash && sb_bits <= 30 && (1ull << sb_bits) <= 4ull * hash_capacity) {
+        uint64_t cap = 1ull << sb_bits;
+        if (cap > leaf_capacity) cap = leaf_capacity;
+        S->I.map = (uint32_t*)S->I.hash;
+        S->I.hash_mask = (uint32_t)((1ull << sb_bits) - 1ull);
+        S->I.leaf_capacity = (uint32_t)cap;
+    } else
+#endif
     // as many leaves as the lattice has superblocks or the cloud has points, whichever is smaller; the
     // table is kept at most half full
     if (S->I.hash) {
@@ -1262,7 +1296,7 @@ __global__ void k_put_ladder(LadderPut P, ScaleDev* __restrict__ ladder, OrderDe
         const uint32_t hmask = S.I.hash_mask, lcap = S.I.leaf_capacity;
         nm_scale_finish(&S, P.radius[t], P.hash_capacity[t], P.leaf_alloc[t], P.allow_dense != 0);
         S.reserved = 0;
-        if (S.I.hash) {
+        if (S.I.hash && !S.I.map) {
             // the host sized this index exactly: keep its numbers
             S.I.hash_mask = hmask;
             S.I.leaf_capacity = lcap;
@@ -1371,7 +1405,8 @@ __global__ __launch_bounds__(256) void k_index_clear_all(const ScaleDev* __restr
         return;
     }
     uint4* h = (uint4*)I.hash;
-    const uint64_t slots = (uint64_t)I.hash_mask + 1ull;
+    // (map form: a word per superblock - a quarter of a quad each; the lattice has at least 2 x 2 x 2 of them)
+    const uint64_t slots = I.map ? ((uint64_t)I.hash_mask + 4ull) / 4ull : (uint64_t)I.hash_mask + 1ull;
     for (uint64_t i = tid; i < slots; i += stride)
         h[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     if (tid < 64) I.counters[tid] = 0u;
