@@ -27,6 +27,20 @@ for k in sorted(tot):
     c = tot[k]
     print(k[:100])
     print("   " + " ".join("%s=%.4g" % (n.replace("SQ_", ""), c[n]) for n in sorted(c)))
+# PMC_MATCH=<kernel name prefix> PMC_LAST=<n>: the last n dispatches of that kernel one by one (a ladder run scale by
+# scale with --fuse-scales 0 launches the search kernel once per scale under one name)
+match, last_n = os.environ.get("PMC_MATCH"), int(os.environ.get("PMC_LAST", "0"))
+if match and last_n:
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(match)]
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-last_n:]
+        for r in rows:
+            if int(r["Dispatch_Id"]) in ids:
+                per[ids.index(int(r["Dispatch_Id"]))][r["Counter_Name"]] += float(r["Counter_Value"])
+    for i in sorted(per):
+        print("dispatch %d of the last %d of %s" % (i, last_n, match))
+        print("   " + " ".join("%s=%.4g" % (n.replace("SQ_", ""), per[i][n]) for n in sorted(per[i])))
 PY
 find $O -name "*counter_collection.csv" -delete
 cat $O/pmc_all.txt
