@@ -156,6 +156,44 @@ def test_golden_forest(golden):
     assert np.array_equal(model.predict(g["x"]), g["label"])
 
 
+def test_forest_leaf_rows_packed_and_padded(golden):
+    # nm_forest::leaf_stride: ForestModel hands over rows of 8 doubles, 64-byte aligned (one cache line per leaf);
+    # a caller's packed (n_leaves, n_classes) table - leaf_stride 0 - must give the same numbers on every evaluator
+    # (the stand-alone one streams trees through LDS above 4096 rows and walks from memory below), and a stride
+    # below n_classes or unaligned 8-double rows are refused
+    import ctypes, copy
+    from nimrud_amd import _ffi, device as nm_device
+    g = golden("g5_forest.npz")
+    model = classification.ForestModel.from_arrays(g)
+    rt = model.rt
+    nc = model._c.n_classes
+    assert model.leaf_stride == 8 and model._c.leaf_stride == 8
+    packed = model.leaf_value[:, :nc].contiguous()
+    rs = np.random.RandomState(5)
+    for n in (len(g["x"]), 20000):
+        x = g["x"] if n == len(g["x"]) else g["x"][rs.randint(0, len(g["x"]), n)]
+        dx = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        want_p, want_l, _ = model._eval(dx, True, True)
+        alt = _ffi.NmForest()
+        ctypes.memmove(ctypes.byref(alt), ctypes.byref(model._c), ctypes.sizeof(_ffi.NmForest))
+        alt.d_leaf_value = packed.data_ptr()
+        alt.leaf_stride = 0
+        proba = torch.empty_like(want_p)
+        label = torch.empty_like(want_l)
+        rt.check(rt.lib.nm_forest_eval(rt.ctx, ctypes.byref(alt), nm_device.ptr(dx), n, dx.shape[1],
+                                       nm_device.ptr(proba), nm_device.ptr(label), rt.stream()))
+        assert torch.equal(proba, want_p) and torch.equal(label, want_l)
+    alt.leaf_stride = nc - 1
+    with pytest.raises(ValueError):
+        rt.check(rt.lib.nm_forest_eval(rt.ctx, ctypes.byref(alt), nm_device.ptr(dx), n, dx.shape[1],
+                                       nm_device.ptr(proba), nm_device.ptr(label), rt.stream()))
+    alt.leaf_stride = 8
+    alt.d_leaf_value = model.leaf_value.data_ptr() + 8          # rows of 8 doubles, off their 64-byte alignment
+    with pytest.raises(ValueError):
+        rt.check(rt.lib.nm_forest_eval(rt.ctx, ctypes.byref(alt), nm_device.ptr(dx), n, dx.shape[1],
+                                       nm_device.ptr(proba), nm_device.ptr(label), rt.stream()))
+
+
 # ---- seeded clouds against the oracle ---------------------------------------------------------------
 
 @pytest.mark.parametrize("ratio", [0.9, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0, 5.2])
