@@ -426,10 +426,11 @@ int nm_forest_eval(nm_ctx* ctx, const nm_forest* forest, const double* d_feat, i
 int nm_set_forest_output(nm_ctx* ctx, const nm_forest* forest, double* d_proba, int64_t proba_stride,
                          int32_t* d_label);
 /* where the forest of nm_set_forest_output runs: 1 (default) in the epilogue of the last search kernel; 0 as a
- * launch of its own directly behind the last scale, over the rows in the ladder's spatial order.  same
- * numbers.  measured on MI355X, 10 M rows x 32 trees: 2.1 ms in the epilogue - the tree walk waits on memory,
- * and there it waits while other waves of the same SIMD run their (vector-ALU bound) search - against 2.9 ms
- * as its own launch and 4.0 ms for nm_forest_eval on the matrix in row order.                          */
+ * launch of its own directly behind the last scale, over the rows in the ladder's spatial order; 2 as a launch of
+ * its own over the finished matrix with the trees streamed through LDS (what nm_forest_eval runs).  same
+ * numbers.  measured on MI355X, 10 M rows x 32 trees (tools/forest_modes.py): 2.1 ms in the epilogue - the tree
+ * walk waits on memory, and there it waits while other waves of the same SIMD run their (vector-ALU bound)
+ * search - against 2.5 ms (mode 0) and 3.0 ms (mode 2; 3.5 ms for a row walk from memory in row order). */
 int nm_set_forest_mode(nm_ctx* ctx, int in_search_kernel);
 
 #ifdef __cplusplus
