@@ -1176,7 +1176,9 @@ __device__ inline void nm_scale_finish(ScaleDev* S, double radius, uint32_t hash
 // from the cloud's extrema (6 doubles on the device) to every scale's lattice.  one thread per scale.
 // `partial` set: the extrema are still the per-block pieces of the bounds pass (k_bounds); this kernel folds
 // them first (what k_bounds_finish does as a launch of its own) and leaves them in `minmax_out`.
-__global__ __launch_bounds__(64) void k_make_ladder(const double* __restrict__ minmax_in,
+constexpr int LADDER_THREADS = 256;     // the fold of up to 1024 per-block extrema is a chain of loads: four waves
+                                        // take four rounds where one took sixteen (10 -> 6 us at 10 M points)
+__global__ __launch_bounds__(LADDER_THREADS) void k_make_ladder(const double* __restrict__ minmax_in,
                                                     const uint64_t* __restrict__ partial, int blocks,
                                                     double* __restrict__ minmax_out, LadderSpec P,
                                                     ScaleDev* __restrict__ ladder, OrderDev* __restrict__ order_dev,
@@ -1191,7 +1193,7 @@ __global__ __launch_bounds__(64) void k_make_ladder(const double* __restrict__ m
             v[a] = ~0ull;
             v[3 + a] = 0ull;
         }
-        for (int b = sc; b < blocks; b += 64) {
+        for (int b = sc; b < blocks; b += LADDER_THREADS) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const uint64_t l = partial[b * 6 + a], h = partial[b * 6 + 3 + a];
@@ -1205,6 +1207,21 @@ __global__ __launch_bounds__(64) void k_make_ladder(const double* __restrict__ m
             for (int a = 0; a < 3; ++a) {
                 const uint64_t l = (uint64_t)__shfl_xor((unsigned long long)v[a], off);
                 const uint64_t h = (uint64_t)__shfl_xor((unsigned long long)v[3 + a], off);
+                v[a] = l < v[a] ? l : v[a];
+                v[3 + a] = h > v[3 + a] ? h : v[3 + a];
+            }
+        }
+        // the four waves' extrema meet in LDS; every thread folds them again (the scale threads need them all)
+        __shared__ uint64_t wave_v[LADDER_THREADS / 64][6];
+        if ((sc & 63) == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) wave_v[sc >> 6][a] = v[a];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            for (int w = 0; w < LADDER_THREADS / 64; ++w) {
+                const uint64_t l = wave_v[w][a], h = wave_v[w][3 + a];
                 v[a] = l < v[a] ? l : v[a];
                 v[3 + a] = h > v[3 + a] ? h : v[3 + a];
             }
@@ -1365,7 +1382,7 @@ int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const void* d_bounds_par
     }
     P.hash_capacity = hash_capacity;
     P.leaf_capacity = leaf_capacity;
-    k_make_ladder<<<1, 64, 0, s>>>(d_minmax, (const uint64_t*)d_bounds_partial, bounds_blocks, d_minmax_out, P,
+    k_make_ladder<<<1, LADDER_THREADS, 0, s>>>(d_minmax, (const uint64_t*)d_bounds_partial, bounds_blocks, d_minmax_out, P,
                                    d_ladder, d_order, ctx->d_status);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
