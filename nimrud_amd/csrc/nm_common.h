@@ -433,6 +433,39 @@ __device__ __forceinline__ void nm_forest_vote(const double* __restrict__ leaf_v
         if (c < nc) acc[c] += val[c];
 }
 
+// part `part` of `parts` of the per-call reset of every index of a ladder (dense: leaves zeroed, all of them count as
+// allocated; map and hash forms: the directory to "empty"; counter blocks to zero), done by `workers` threads of
+// which this is number `worker`.  one kernel of its own (k_index_clear_all), or thirds of it ridden along by the
+// blocks appended to the spatial sort's three counting kernels, whose bandwidth is idle (nm_order.hip)
+__device__ __forceinline__ void nm_index_clear_part(const ScaleDev* __restrict__ ladder, int32_t n_scales,
+                                                    uint64_t worker, uint64_t workers, int part, int parts)
+{
+    for (int32_t sc = 0; sc < n_scales; ++sc) {
+        if (ladder[sc].shared) {
+            // a borrowed index is cleared by its owner; the borrower's own counter block holds its statistics
+            if (part == 0 && worker < 64) ladder[sc].stats[worker] = 0u;
+            continue;
+        }
+        const IndexDev I = ladder[sc].I;
+        uint4* base;
+        uint64_t quads;
+        uint4 fill;
+        if (!I.hash) {
+            base = (uint4*)I.leaf;
+            quads = ((uint64_t)I.hash_mask + 1ull) * (NM_LEAF_WORDS / 4);
+            fill = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            // (map form: a word per superblock - a quarter of a quad each)
+            base = (uint4*)I.hash;
+            quads = I.map ? ((uint64_t)I.hash_mask + 4ull) / 4ull : (uint64_t)I.hash_mask + 1ull;
+            fill = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+        const uint64_t lo = quads * (uint64_t)part / (uint64_t)parts, hi = quads * (uint64_t)(part + 1) / (uint64_t)parts;
+        for (uint64_t i = lo + worker; i < hi; i += workers) base[i] = fill;
+        if (part == 0 && worker < 64) I.counters[worker] = (!I.hash && worker == 0) ? I.hash_mask + 1u : 0u;
+    }
+}
+
 // XCD-aware block -> batch mapping: workgroups are dealt round-robin over the 8 XCDs, so give every
 // XCD one contiguous eighth of the batches; neighbouring batches then share that XCD's L2.  bijective for
 // any grid size.

@@ -33,6 +33,9 @@ constexpr int ANCHOR_EYZ = 22;  // y/z extent of the fallback box around an anch
 #ifndef NM_FUSE_GATHER
 #define NM_FUSE_GATHER 1        // the index builder gathers the coordinates into sorted order itself
 #endif
+#ifndef NM_FUSE_CLEAR
+#define NM_FUSE_CLEAR 1         // the spatial sort's counting kernels reset the ladder's indexes (no clear launch)
+#endif
 #ifndef NM_DIAG_SUMS
 #define NM_DIAG_SUMS 0          // row walk: sum j*k*n from per-(j+k) sums (adds) instead of a multiply-add per row
 #endif
@@ -2255,9 +2258,11 @@ static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, c
     const OrderDev* d_order = (const OrderDev*)(w + S.order_dev);
     // (the search cloud's coordinates are gathered into sorted order by the index builder below: no gather
     // kernel, one read of the sorted copy less.  NM_FUSE_GATHER = 0: a gather kernel behind the sort)
+    // (the sort's counting kernels reset the indexes on the way: NM_FUSE_CLEAR)
     int rc = nm_order_build(ctx, C.d_search, C.n_search, C.search_stride, d_order, w + S.order_scratch,
                             S.order_scratch_bytes, (uint32_t*)(w + S.s_order),
-                            NM_FUSE_GATHER ? nullptr : (double*)(w + S.s_xyz), s);
+                            NM_FUSE_GATHER ? nullptr : (double*)(w + S.s_xyz), s,
+                            NM_FUSE_CLEAR ? d_ladder : nullptr, C.n_scales);
     if (rc) return rc;
     const uint32_t* q_order = (const uint32_t*)(w + S.s_order);
     const double* q_xyz = (const double*)(w + S.s_xyz);
@@ -2271,8 +2276,10 @@ static int run_ladder(nm_ctx* ctx, const LadderCall& C, const LadderLayout& S, c
     nm_profile_mark(ctx, s);           // end of the "order" stage
     // every scale has its own index; one launch clears them all, one builds them all (the block keeps its
     // points and walks the scales), one counts them all at the end
-    rc = nm_index_clear_all(ctx, d_ladder, C.n_scales, s);
-    if (rc) return rc;
+    if (!NM_FUSE_CLEAR) {
+        rc = nm_index_clear_all(ctx, d_ladder, C.n_scales, s);
+        if (rc) return rc;
+    }
     if (NM_FUSE_GATHER)
         rc = nm_index_build_ladder_gather(ctx, C.d_search, C.n_search, C.search_stride,
                                           (const uint32_t*)(w + S.s_order), (double*)(w + S.s_xyz), d_ladder, 0,

@@ -23,10 +23,13 @@ int nm_index_build(nm_ctx* ctx, const uint64_t* key_sorted, int64_t n, const Ind
 // whole-ladder path: one spatial order for all scales, every scale described by a ScaleDev in device memory.
 // order[i] = original row of sorted slot i (sorted by the compact cell key of the lattice in *d_order_dev,
 // nm_order.hip), sorted_xyz = the coordinates in that order, (n,3) contiguous - or null: the caller gathers them
-// itself (nm_index_build_ladder_gather).  scratch: nm_order_scratch_bytes(n)
+// itself (nm_index_build_ladder_gather).  scratch: nm_order_scratch_bytes(n).  clear_ladder: the sort's three
+// counting kernels also reset the indexes of that ladder, a third each (what nm_index_clear_all does as a launch
+// of its own) - the caller then does not launch the clear
 size_t nm_order_scratch_bytes(int64_t n);
 int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const OrderDev* d_order_dev,
-                   void* scratch, size_t scratch_bytes, uint32_t* order, double* sorted_xyz, hipStream_t s);
+                   void* scratch, size_t scratch_bytes, uint32_t* order, double* sorted_xyz, hipStream_t s,
+                   const ScaleDev* clear_ladder = nullptr, int clear_scales = 0);
 
 // the extrema of a cloud (nm_bounds) with NM_BOUNDS_SCRATCH_BYTES of caller scratch: no atomics
 constexpr size_t NM_BOUNDS_SCRATCH_BYTES = 1024 * 6 * 8;

@@ -1408,28 +1408,9 @@ IndexDev nm_index_at(nm_ctx* ctx, void* index_mem, const IndexLayout& lay)
 // hash tables to all ones (free), counter blocks to zero
 __global__ __launch_bounds__(256) void k_index_clear_all(const ScaleDev* __restrict__ ladder)
 {
-    const IndexDev I = ladder[blockIdx.y].I;
-    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    if (ladder[blockIdx.y].shared) {
-        // a borrowed index is cleared by its owner; the borrower's own counter block holds its statistics
-        if (tid < 64) ladder[blockIdx.y].stats[tid] = 0u;
-        return;
-    }
-    if (!I.hash) {
-        // dense: every superblock's leaf, zeroed; all of them count as allocated
-        uint4* l = (uint4*)I.leaf;
-        const uint64_t quads = ((uint64_t)I.hash_mask + 1ull) * (NM_LEAF_WORDS / 4);
-        for (uint64_t i = tid; i < quads; i += stride) l[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (tid < 64) I.counters[tid] = tid == 0 ? I.hash_mask + 1u : 0u;
-        return;
-    }
-    uint4* h = (uint4*)I.hash;
-    // (map form: a word per superblock - a quarter of a quad each; the lattice has at least 2 x 2 x 2 of them)
-    const uint64_t slots = I.map ? ((uint64_t)I.hash_mask + 4ull) / 4ull : (uint64_t)I.hash_mask + 1ull;
-    for (uint64_t i = tid; i < slots; i += stride)
-        h[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (tid < 64) I.counters[tid] = 0u;
+    // (a column of blocks per scale: the scales are cleared side by side)
+    nm_index_clear_part(ladder + blockIdx.y, 1, blockIdx.x * (uint64_t)blockDim.x + threadIdx.x,
+                        (uint64_t)gridDim.x * blockDim.x, 0, 1);
 }
 
 // M of every index (set bits of its allocated leaves)

@@ -117,9 +117,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_order_keys_hist(const double* 
                                                                   int64_t stride,
                                                                   const OrderDev* __restrict__ od,
                                                                   uint32_t* __restrict__ keys,
-                                                                  uint32_t* __restrict__ H, int32_t hstride)
+                                                                  uint32_t* __restrict__ H, int32_t hstride,
+                                                                  int32_t tiles, const ScaleDev* __restrict__ ladder,
+                                                                  int32_t n_scales)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
+    // blocks appended behind the tiles' reset a third of the ladder's indexes: one launch less per step (3-6 us: what a
+    // small cloud's step notices).  the 0.3 GB of a 10 M-point ladder do NOT hide in here - the counting kernels
+    // lengthen by what the clear kernel took, leading blocks instead of trailing ones make it worse (measured) - the
+    // memory system is busy with the kernels' own reads
+    if ((int32_t)blockIdx.x >= tiles) {
+        nm_index_clear_part(ladder, n_scales, (uint64_t)(blockIdx.x - tiles) * SORT_THREADS + threadIdx.x,
+                            (uint64_t)(gridDim.x - tiles) * SORT_THREADS, 0, 3);
+        return;
+    }
     __shared__ uint32_t lh[SORT_BINS];
     const int tid = threadIdx.x;
     const int32_t tile = blockIdx.x;
@@ -141,8 +152,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_order_keys_hist(const double* 
     __syncthreads();
     H[(size_t)tid * hstride + tile] = lh[tid];
     H[(size_t)(tid + SORT_THREADS) * hstride + tile] = lh[tid + SORT_THREADS];
-    if (tile == (int32_t)gridDim.x - 1)       // the padding columns of every row (the scan runs in place)
-        for (int32_t pad = (int32_t)gridDim.x; pad < hstride; ++pad) {
+    if (tile == tiles - 1)       // the padding columns of every row (the scan runs in place)
+        for (int32_t pad = tiles; pad < hstride; ++pad) {
             H[(size_t)tid * hstride + pad] = 0u;
             H[(size_t)(tid + SORT_THREADS) * hstride + pad] = 0u;
         }
@@ -152,9 +163,16 @@ __global__ __launch_bounds__(SORT_THREADS) void k_order_keys_hist(const double* 
 template <int ITEMS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint2* __restrict__ pairs, int64_t n,
                                                             int pass, const OrderDev* __restrict__ od,
-                                                            uint32_t* __restrict__ H, int32_t hstride)
+                                                            uint32_t* __restrict__ H, int32_t hstride,
+                                                            int32_t tiles, const ScaleDev* __restrict__ ladder,
+                                                            int32_t n_scales)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
+    if ((int32_t)blockIdx.x >= tiles) {       // appended blocks: this pass's third of the index reset
+        nm_index_clear_part(ladder, n_scales, (uint64_t)(blockIdx.x - tiles) * SORT_THREADS + threadIdx.x,
+                            (uint64_t)(gridDim.x - tiles) * SORT_THREADS, pass, 3);
+        return;
+    }
     if (pass >= od->passes) return;       // a short key is sorted in two passes: the third one's launches leave
     __shared__ uint32_t lh[SORT_BINS];
     const int tid = threadIdx.x;
@@ -173,8 +191,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint2* __restr
     __syncthreads();
     H[(size_t)tid * hstride + tile] = lh[tid];
     H[(size_t)(tid + SORT_THREADS) * hstride + tile] = lh[tid + SORT_THREADS];
-    if (tile == (int32_t)gridDim.x - 1)       // the padding columns of every row (the scan runs in place)
-        for (int32_t pad = (int32_t)gridDim.x; pad < hstride; ++pad) {
+    if (tile == tiles - 1)       // the padding columns of every row (the scan runs in place)
+        for (int32_t pad = tiles; pad < hstride; ++pad) {
             H[(size_t)tid * hstride + pad] = 0u;
             H[(size_t)(tid + SORT_THREADS) * hstride + pad] = 0u;
         }
@@ -506,7 +524,8 @@ size_t nm_order_scratch_bytes(int64_t n)
 
 template <int ITEMS, bool DIRECT>
 static int order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const OrderDev* od,
-                       const OrderScratch& S, char* w, uint32_t* order, double* sorted_xyz, hipStream_t s)
+                       const OrderScratch& S, char* w, uint32_t* order, double* sorted_xyz,
+                       const ScaleDev* clear_ladder, int clear_scales, hipStream_t s)
 {
     uint32_t* keys = (uint32_t*)(w + S.keys);
     uint2* pa = (uint2*)(w + S.pairs_a);
@@ -531,17 +550,27 @@ static int order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stri
     };
     SortIO io{};
     io.order_out = order;          // whichever pass is the key's last writes the permutation
-    k_order_keys_hist<ITEMS><<<tiles, SORT_THREADS, 0, s>>>(d_xyz, n, stride, od, keys, H, S.hstride);
+    // blocks appended to the three counting kernels reset a third each of the ladder's indexes (when asked to)
+    int extra = 0;
+    if (clear_ladder) {
+        extra = tiles / 2;
+        if (extra < 8) extra = 8;
+        if (extra > 512) extra = 512;
+    }
+    k_order_keys_hist<ITEMS><<<tiles + extra, SORT_THREADS, 0, s>>>(d_xyz, n, stride, od, keys, H, S.hstride, tiles,
+                                                                     clear_ladder, clear_scales);
     scan(0);
     io.keys_in = keys;
     io.pairs_out = pa;
     k_sort_scatter<0, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
-    k_sort_hist<ITEMS><<<tiles, SORT_THREADS, 0, s>>>(pa, n, 1, od, H, S.hstride);
+    k_sort_hist<ITEMS><<<tiles + extra, SORT_THREADS, 0, s>>>(pa, n, 1, od, H, S.hstride, tiles, clear_ladder,
+                                                               clear_scales);
     scan(1);
     io.pairs_in = pa;
     io.pairs_out = pb;
     k_sort_scatter<1, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
-    k_sort_hist<ITEMS><<<tiles, SORT_THREADS, 0, s>>>(pb, n, 2, od, H, S.hstride);
+    k_sort_hist<ITEMS><<<tiles + extra, SORT_THREADS, 0, s>>>(pb, n, 2, od, H, S.hstride, tiles, clear_ladder,
+                                                               clear_scales);
     scan(2);
     io.pairs_in = pb;
     io.pairs_out = nullptr;
@@ -552,7 +581,8 @@ static int order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stri
 }
 
 int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, const OrderDev* d_order_dev,
-                   void* scratch, size_t scratch_bytes, uint32_t* order, double* sorted_xyz, hipStream_t s)
+                   void* scratch, size_t scratch_bytes, uint32_t* order, double* sorted_xyz, hipStream_t s,
+                   const ScaleDev* clear_ladder, int clear_scales)
 {
     OrderScratch S;
     order_scratch(n, &S);
@@ -560,12 +590,16 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
     char* w = (char*)scratch;
     if (S.items == SORT_ITEMS_BIG) {
         if (S.tiles <= SORT_DIRECT_TILES)
-            return order_build<SORT_ITEMS_BIG, true>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, s);
-        return order_build<SORT_ITEMS_BIG, false>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, s);
+            return order_build<SORT_ITEMS_BIG, true>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, clear_ladder,
+                                                     clear_scales, s);
+        return order_build<SORT_ITEMS_BIG, false>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, clear_ladder,
+                                                     clear_scales, s);
     }
     if (S.tiles <= SORT_DIRECT_TILES)
-        return order_build<SORT_ITEMS_SMALL, true>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, s);
-    return order_build<SORT_ITEMS_SMALL, false>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, s);
+        return order_build<SORT_ITEMS_SMALL, true>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, clear_ladder,
+                                                     clear_scales, s);
+    return order_build<SORT_ITEMS_SMALL, false>(ctx, d_xyz, n, stride, d_order_dev, S, w, order, sorted_xyz, clear_ladder,
+                                                     clear_scales, s);
 }
 
 // ---- the order as an entry point of its own (inspection, tests) ------------------------------------------------------
