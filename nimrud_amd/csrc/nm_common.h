@@ -85,6 +85,8 @@ struct nm_ctx {
     int64_t halo_n = -1;
     const void* halo_work = nullptr;
     int64_t halo_host_syncs = 0, halo_exchanges = 0;
+    int64_t order_points = 0;       // points of the largest cloud of the call in progress: decides the sort's pass count
+                                    // on the host (nm_order_plan's rule; set by the entry points)
     uint32_t order_attr_set = 0;    // spatial sort: kernel families whose dynamic-LDS attribute is set (nm_order.hip)
 };
 
@@ -298,7 +300,12 @@ struct OrderDev {
 constexpr int NM_ORDER_PASS_BITS = 10;
 
 // the spatial order of a lattice: which key, how its bits are laid out, what is dropped to fit the sort key
-__host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O)
+// `points`: the size of the largest cloud the order will be built for.  up to NM_ORDER_TWO_PASS_N points the key
+// keeps 20 bits - a million key values, one point or two to a value: which 64 points are a wave's is decided by
+// the bits above - and is sorted in TWO passes, which the host then knows without asking the device: it launches
+// two (the third pass's three launches were a tenth of a small cloud's step)
+constexpr int64_t NM_ORDER_TWO_PASS_N = (int64_t)1 << 21;
+__host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O, int64_t points)
 {
     O->L = L;
     int wmax = L.wx > L.wy ? L.wx : L.wy;
@@ -321,7 +328,8 @@ __host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O)
         }
     }
     const int bits = O->morton ? L.wx + L.wy + L.wz : L.keybits;
-    O->shift = bits > NM_ORDER_KEY_BITS ? bits - NM_ORDER_KEY_BITS : 0;
+    const int key_bits = points > 0 && points <= NM_ORDER_TWO_PASS_N ? 2 * NM_ORDER_PASS_BITS : NM_ORDER_KEY_BITS;
+    O->shift = bits > key_bits ? bits - key_bits : 0;
     const int kept = bits - O->shift;
     O->passes = kept <= 2 * NM_ORDER_PASS_BITS ? 2 : 3;
     int bpp = (kept + O->passes - 1) / O->passes;

@@ -2445,6 +2445,7 @@ extern "C" int nm_multiscale_features(nm_ctx* ctx, const double* d_query, int64_
         I[i].leaf_capacity = lay.leaf_capacity;
         I[i].status = ctx->d_status;
     }
+    ctx->order_points = n_query > n_search ? n_query : n_search;     // (the sort's pass count: nm_order_plan)
     rc = nm_ladder_put(ctx, L, I, radii, n_scales, finest, S.leaf_capacity, (ScaleDev*)(w + S.ladder),
                        (OrderDev*)(w + S.order_dev), s);
     if (rc) return rc;
@@ -2498,6 +2499,7 @@ extern "C" int nm_ladder_features(nm_ctx* ctx, const double* d_query, int64_t n_
         leaf[i] = w + S.leaf[i];
         counters[i] = w + S.counters[i];
     }
+    ctx->order_points = n_query > n_search ? n_query : n_search;     // (the sort's pass count: nm_order_plan)
     rc = nm_ladder_make(ctx, d_minmax, partial, bounds_blocks, (double*)(w + S.minmax), edges, radii, n_scales,
                         finest, hash, leaf, counters, S.hash_capacity, S.leaf_capacity,
                         (ScaleDev*)(w + S.ladder), (OrderDev*)(w + S.order_dev), s);

@@ -1122,6 +1122,7 @@ struct LadderSpec {
     uint32_t* counters[NM_MAX_LADDER];
     uint32_t hash_capacity;            // slots allocated per scale (power of two)
     uint32_t leaf_capacity;            // leaves allocated per scale
+    int64_t order_points;              // nm_order_plan's point count
 };
 
 __device__ inline void nm_scale_finish(ScaleDev* S, double radius, uint32_t hash_capacity,
@@ -1289,7 +1290,7 @@ __global__ __launch_bounds__(LADDER_THREADS) void k_make_ladder(const double* __
         ladder[sc] = S;
         if (sc == P.finest) {
             OrderDev O;
-            nm_order_plan(S.L, &O);
+            nm_order_plan(S.L, &O, P.order_points);
             O.valid = S.valid;
             *order_dev = O;
         }
@@ -1305,6 +1306,7 @@ struct LadderPut {
     ScaleDev scale[8];                 // (stats / shared filled in by the host: nm_ladder_put)
     double radius[8];
     uint32_t hash_capacity[8], leaf_alloc[8];      // slots of the table, leaves the workspace has room for
+    int64_t order_points;              // nm_order_plan's point count
 };
 
 __global__ void k_put_ladder(LadderPut P, ScaleDev* __restrict__ ladder, OrderDev* __restrict__ order_dev)
@@ -1324,7 +1326,7 @@ __global__ void k_put_ladder(LadderPut P, ScaleDev* __restrict__ ladder, OrderDe
         ladder[P.first + t] = S;
         if (order_dev && P.first + t == P.finest) {
             OrderDev O;
-            nm_order_plan(S.L, &O);
+            nm_order_plan(S.L, &O, P.order_points);
             *order_dev = O;
         }
     }
@@ -1339,6 +1341,7 @@ int nm_ladder_put(nm_ctx* ctx, const LatticeDev* L, const IndexDev* I, const dou
         P.n_scales = n_scales - first < 8 ? n_scales - first : 8;
         P.first = first;
         P.finest = finest;
+        P.order_points = ctx->order_points;
         for (int t = 0; t < P.n_scales; ++t) {
             // same lattice as an earlier scale (same edge, hence same corner and widths): borrow its index
             int owner = first + t;
@@ -1382,6 +1385,7 @@ int nm_ladder_make(nm_ctx* ctx, const double* d_minmax, const void* d_bounds_par
     }
     P.hash_capacity = hash_capacity;
     P.leaf_capacity = leaf_capacity;
+    P.order_points = ctx->order_points;
     k_make_ladder<<<1, LADDER_THREADS, 0, s>>>(d_minmax, (const uint64_t*)d_bounds_partial, bounds_blocks, d_minmax_out, P,
                                    d_ladder, d_order, ctx->d_status);
     NM_HIP(ctx, hipGetLastError());

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_order_keys_hist(const double* 
                                                                   uint32_t* __restrict__ keys,
                                                                   uint32_t* __restrict__ H, int32_t hstride,
                                                                   int32_t tiles, const ScaleDev* __restrict__ ladder,
-                                                                  int32_t n_scales)
+                                                                  int32_t n_scales, int32_t parts)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
     // blocks appended behind the tiles' reset a third of the ladder's indexes: one launch less per step (3-6 us: what a
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_order_keys_hist(const double* 
     // memory system is busy with the kernels' own reads
     if ((int32_t)blockIdx.x >= tiles) {
         nm_index_clear_part(ladder, n_scales, (uint64_t)(blockIdx.x - tiles) * SORT_THREADS + threadIdx.x,
-                            (uint64_t)(gridDim.x - tiles) * SORT_THREADS, 0, 3);
+                            (uint64_t)(gridDim.x - tiles) * SORT_THREADS, 0, parts);
         return;
     }
     __shared__ uint32_t lh[SORT_BINS];
@@ -165,12 +165,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint2* __restr
                                                             int pass, const OrderDev* __restrict__ od,
                                                             uint32_t* __restrict__ H, int32_t hstride,
                                                             int32_t tiles, const ScaleDev* __restrict__ ladder,
-                                                            int32_t n_scales)
+                                                            int32_t n_scales, int32_t parts)
 {
     constexpr int TILE = SORT_THREADS * ITEMS;
     if ((int32_t)blockIdx.x >= tiles) {       // appended blocks: this pass's third of the index reset
         nm_index_clear_part(ladder, n_scales, (uint64_t)(blockIdx.x - tiles) * SORT_THREADS + threadIdx.x,
-                            (uint64_t)(gridDim.x - tiles) * SORT_THREADS, pass, 3);
+                            (uint64_t)(gridDim.x - tiles) * SORT_THREADS, pass, parts);
         return;
     }
     if (pass >= od->passes) return;       // a short key is sorted in two passes: the third one's launches leave
@@ -548,9 +548,13 @@ static int order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stri
         k_scan_reduce<<<S.scan_blocks, SCAN_THREADS, 0, s>>>(H, S.hist_len, partial, pass, od);
         k_scan_apply<<<S.scan_blocks, SCAN_THREADS, 0, s>>>(H, S.hist_len, partial, pass, od);
     };
+    // (the host's half of nm_order_plan's rule: a cloud this small is sorted in two passes - the plan keeps 20 key
+    // bits - so the third pass's launches are not made; above, the device decides and a short key's third pass leaves)
+    const bool two = ctx->order_points > 0 && ctx->order_points <= NM_ORDER_TWO_PASS_N;
+    const int parts = two ? 2 : 3;          // counting kernels that share the index reset
     SortIO io{};
     io.order_out = order;          // whichever pass is the key's last writes the permutation
-    // blocks appended to the three counting kernels reset a third each of the ladder's indexes (when asked to)
+    // blocks appended to the counting kernels reset a share each of the ladder's indexes (when asked to)
     int extra = 0;
     if (clear_ladder) {
         extra = tiles / 2;
@@ -558,23 +562,25 @@ static int order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stri
         if (extra > 512) extra = 512;
     }
     k_order_keys_hist<ITEMS><<<tiles + extra, SORT_THREADS, 0, s>>>(d_xyz, n, stride, od, keys, H, S.hstride, tiles,
-                                                                     clear_ladder, clear_scales);
+                                                                     clear_ladder, clear_scales, parts);
     scan(0);
     io.keys_in = keys;
     io.pairs_out = pa;
     k_sort_scatter<0, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
     k_sort_hist<ITEMS><<<tiles + extra, SORT_THREADS, 0, s>>>(pa, n, 1, od, H, S.hstride, tiles, clear_ladder,
-                                                               clear_scales);
+                                                               clear_scales, parts);
     scan(1);
     io.pairs_in = pa;
     io.pairs_out = pb;
     k_sort_scatter<1, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
-    k_sort_hist<ITEMS><<<tiles + extra, SORT_THREADS, 0, s>>>(pb, n, 2, od, H, S.hstride, tiles, clear_ladder,
-                                                               clear_scales);
-    scan(2);
-    io.pairs_in = pb;
-    io.pairs_out = nullptr;
-    k_sort_scatter<2, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
+    if (!two) {
+        k_sort_hist<ITEMS><<<tiles + extra, SORT_THREADS, 0, s>>>(pb, n, 2, od, H, S.hstride, tiles, clear_ladder,
+                                                                   clear_scales, parts);
+        scan(2);
+        io.pairs_in = pb;
+        io.pairs_out = nullptr;
+        k_sort_scatter<2, ITEMS, DIRECT><<<tiles, SORT_THREADS, LDS, s>>>(io, n, tiles, S.hstride, H, od);
+    }
     if (sorted_xyz) k_gather_xyz<<<(int)((n + 255) / 256), 256, 0, s>>>(d_xyz, n, stride, order, sorted_xyz);
     NM_HIP(ctx, hipGetLastError());
     return NM_OK;
@@ -603,11 +609,11 @@ int nm_order_build(nm_ctx* ctx, const double* d_xyz, int64_t n, int64_t stride, 
 }
 
 // ---- the order as an entry point of its own (inspection, tests) ------------------------------------------------------
-__global__ void k_order_plan(LatticeDev L, OrderDev* out)
+__global__ void k_order_plan(LatticeDev L, OrderDev* out, int64_t points)
 {
     if (threadIdx.x == 0) {
         OrderDev O;
-        nm_order_plan(L, &O);
+        nm_order_plan(L, &O, points);
         *out = O;
     }
 }
@@ -640,7 +646,8 @@ extern "C" int nm_spatial_order(nm_ctx* ctx, const double* d_xyz, int64_t n, int
     hipStream_t s = (hipStream_t)stream;
     OrderDev* od = (OrderDev*)d_work;
     char* scratch = (char*)d_work + align_up(sizeof(OrderDev));
-    k_order_plan<<<1, 64, 0, s>>>(make_lattice_dev(lat), od);
+    ctx->order_points = n;
+    k_order_plan<<<1, 64, 0, s>>>(make_lattice_dev(lat), od, n);
     rc = nm_order_build(ctx, d_xyz, n, stride, od, scratch, work_bytes - align_up(sizeof(OrderDev)), d_order,
                         d_sorted_xyz, s);
     if (rc) return rc;
