@@ -301,10 +301,13 @@ constexpr int NM_ORDER_PASS_BITS = 10;
 
 // the spatial order of a lattice: which key, how its bits are laid out, what is dropped to fit the sort key
 // `points`: the size of the largest cloud the order will be built for.  up to NM_ORDER_TWO_PASS_N points the key
-// keeps 20 bits - a million key values, one point or two to a value: which 64 points are a wave's is decided by
+// keeps 20 bits - a million key values, a few points to a value: which 64 points are a wave's is decided by
 // the bits above - and is sorted in TWO passes, which the host then knows without asking the device: it launches
 // two (the third pass's three launches were a tenth of a small cloud's step)
-constexpr int64_t NM_ORDER_TWO_PASS_N = (int64_t)1 << 21;
+#ifndef NM_ORDER_TWO_PASS_LOG2
+#define NM_ORDER_TWO_PASS_LOG2 22
+#endif
+constexpr int64_t NM_ORDER_TWO_PASS_N = (int64_t)1 << NM_ORDER_TWO_PASS_LOG2;
 __host__ __device__ inline void nm_order_plan(const LatticeDev& L, OrderDev* O, int64_t points)
 {
     O->L = L;

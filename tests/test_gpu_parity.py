@@ -1503,7 +1503,7 @@ def _compact_zorder_key(cells, widths, key_bits=30):
 
 @pytest.mark.parametrize("n,edge,kind", [(1, 0.1, "uniform"), (300, 0.1, "uniform"), (8192, 0.05, "uniform"),
                                          (8193, 0.05, "scene"), (250_000, 0.25, "uniform"),
-                                         (2_000_003, 0.05, "scene"), (2_500_000, 0.05, "scene")])
+                                         (2_000_003, 0.05, "scene"), (4_500_000, 0.05, "scene")])
 def test_spatial_order_is_a_sorted_permutation(n, edge, kind):
     """nm_spatial_order: the permutation is one, the coordinates are carried along bit for bit, the keys the
     library reports are the compact Z-order keys of the cells (restated in numpy above) and they come out
@@ -1536,9 +1536,9 @@ def test_spatial_order_is_a_sorted_permutation(n, edge, kind):
     assert np.array_equal(sxyz.cpu().numpy(), pts[order])
     got = keys.cpu().numpy().view(np.uint32)
     cells = np.floor((pts[order] - mc) / edge).astype(np.int64)
-    # (clouds of up to 2^21 points keep 20 key bits and are sorted in two passes, larger ones 30 and three:
+    # (clouds of up to 2^22 points keep 20 key bits and are sorted in two passes, larger ones 30 and three:
     # nm_order_plan)
-    key_bits = 20 if n <= (1 << 21) else 30
+    key_bits = 20 if n <= (1 << 22) else 30
     want = _compact_zorder_key(cells, widths, key_bits)
     # the library takes the cell from a multiplication by fl(1/e): a point within rounding of a cell face may
     # carry its neighbour's key
