@@ -47,6 +47,10 @@ constexpr int NM_BOX_EX = 62;   // x extent of a staged box: 64-bit rows, kept s
 #define NM_KEEP_QUERY 1         // the query stays in registers across the scale loop: 0 never, 1 not with the forest
                                 // epilogue (97 registers there: a wave of occupancy), 2 always
 #endif
+#ifndef NM_SPLIT_SCALES_BELOW
+#define NM_SPLIT_SCALES_BELOW 1600000     // (slots) the search kernel is launched with a workgroup per (scale, batch) up to here:
+                                          // 300 k points -31 %, 1.25 M -7 %, 2.5 M +8 % (the queries are read per scale again)
+#endif
 #ifndef NM_ADAPTIVE_ANCHOR
 #define NM_ADAPTIVE_ANCHOR 1    // the fallback box around an anchor lane takes its shape from the pending lanes' box
 #endif
@@ -1009,7 +1013,13 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
     const int32_t dmin = A.dmin;
     const int32_t dmax = dmin + W - 1;
 
-    const int64_t batch = nm_xcd_batch(blockIdx.x, gridDim.x);
+    // LOOP = false: one scale per workgroup.  a launch may then cover several scales, workgroups (scale, batch) with
+    // the scale the slow index (small clouds: a 1.25 M-point tile's 19 531 waves of five scales each are 3.8 rounds
+    // of the card's wave slots, and the last round's tail is a tenth of the kernel; 97 656 fifths are 19 rounds)
+    const int64_t n_batches = (A.n_slots + 63) / 64;
+    const int32_t s_first = LOOP ? A.s_begin : A.s_begin + (int32_t)((int64_t)blockIdx.x / n_batches);
+    const int64_t batch = LOOP ? nm_xcd_batch(blockIdx.x, gridDim.x)
+                               : nm_xcd_batch((int64_t)blockIdx.x % n_batches, n_batches);
     // the moment table comes from constant data (computing it cost every wave ~70 vector instructions)
     for (int m = lane; m < (1 << W); m += 64) lut[m] = NM_LUT<W>.v[m];
 
@@ -1033,7 +1043,7 @@ __global__ __launch_bounds__(64) NM_SEARCH_ATTR void k_scale_features(ScaleArgs 
         qz0 = p[2];
     }
 #pragma nounroll
-    for (int32_t s = A.s_begin; s < (LOOP ? A.s_end : A.s_begin + 1); ++s) {
+    for (int32_t s = s_first; s < (LOOP ? A.s_end : s_first + 1); ++s) {
     bool have = have0;
     double qx = qx0, qy = qy0, qz = qz0;
     if (!KEEPQ && have) {
@@ -1967,7 +1977,11 @@ static bool launch_scale_kernel(const ScaleArgs& A, double radius, double edge, 
         // table kernel's epilogue needs every column of the row
         k_scale_features_generic<true><<<blocks < 2048 ? blocks : 2048, 64, 0, s>>>(A);
         const bool loop = A.s_end - A.s_begin > 1;
+        // small clouds: a workgroup per (scale, batch) instead of a wave walking the scales - shorter workgroups, a
+        // shorter tail (NM_SPLIT_SCALES_BELOW slots; above, keeping the queries in registers across the loop wins)
+        const bool split = loop && !forest && A.n_slots <= NM_SPLIT_SCALES_BELOW;
         if (forest) launch_table_kernel<true, true>(A, rho, W, blocks, s);
+        else if (split) launch_table_kernel<false, false>(A, rho, W, blocks * (A.s_end - A.s_begin), s);
         else if (loop) launch_table_kernel<false, true>(A, rho, W, blocks, s);
         else launch_table_kernel<false, false>(A, rho, W, blocks, s);
         return forest;
